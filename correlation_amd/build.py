@@ -1,0 +1,54 @@
+"""Build the gfx950 engine library in-tree (correlation_amd/liblk_engine.so).
+
+hipcc cross-compiles without a GPU; the .so travels to the GPU box with the snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "liblk_engine.so")
+SOURCES = ["lk_engine.cpp", "lk_kernels.hip"]
+HEADERS = ["lk_device.hpp", "lk_roi.hpp", os.path.join("..", "..", "include", "lk_engine.h")]
+
+
+def hipcc_path():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into liblk_engine.so."""
+    if not force and not needs_build():
+        return LIB
+    cmd = [
+        hipcc_path(), "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",
+        # the reference's x86-64 builds have no FMA: keep mul and add separate unless the
+        # source asks for an fma explicitly (see lk_kernels.hip header)
+        "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+        "-Wall", "-Wextra", "-o", LIB,
+    ] + SOURCES
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed building liblk_engine.so")
+    if verbose:
+        sys.stderr.write(r.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

@@ -1,0 +1,40 @@
+// lk_device.hpp - shared host/device structs of the gfx950 Lucas-Kanade engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lk_engine.h"
+
+// One pyramid level as the solve kernel sees it.  Images are row-major u8 with
+// pitch == cols (pyramid_class.cpp:153,177: step = cols) and two zeroed guard rows.
+struct LkLevelView {
+  const uint8_t *und;  // undeformed image, level L
+  const uint8_t *def;  // deformed image, level L
+  const float2 *xy;    // concatenated per-sector sample lists of level L (AoS x,y)
+  const uint32_t *off; // [S+1] start of each sector's list in xy
+  int urows, ucols;    // und dims at this level (rows0 >> L, pyramid_class.cpp:447-477)
+  int drows, dcols;    // def dims
+};
+
+struct LkSolveArgs {
+  const LkLevelView *lv; // [LK_MAX_LEVELS] in device memory
+  const float2 *center;  // [S] level-0 centre of each sector
+  const float *guess;    // [S][6]
+  lk_result *result;     // [S]
+  float *last_p;         // [S][6] copy of the returned parameters (sequence state), may be null
+  uint32_t *stats;       // [S][4]: evaluations, sample evaluations, point iterations, -
+  const uint32_t *order; // optional [n_sectors] indirection (size classes), may be null
+  int n_sectors;         // sectors in this launch
+  int chunk;             // ceil(n_sectors / 8): XCD-contiguous chunk length
+  int py_start, py_step, py_stop;
+  float precision;
+  int max_iters;
+};
+
+struct LkEvalArgs { // stand-alone evaluation (known-answer tests)
+  const LkLevelView *lv;
+  const float2 *center;
+  int sector, level;
+  float p[6];
+  float *out; // [36 + 6 + 1 + 1]: A row-major 6x6 (upper), b, chi, error
+};

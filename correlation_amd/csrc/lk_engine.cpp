@@ -1,0 +1,920 @@
+// lk_engine.cpp - host side of the gfx950 Lucas-Kanade engine behind include/lk_engine.h.
+//
+// What lives where (HBM layout, one engine per GPU):
+//   images      3 slots (und, def, nxt) x (py_stop+1) levels, row-major u8, pitch = cols,
+//               two zeroed guard rows per level.  2048^2: 4 MiB + 1 MiB + 256 KiB per slot.
+//   sample lists per level L: one concatenated float2 array + uint32 offsets [S+1]
+//               (level 0 = the ROI's samples in the CPU engine's order, level L = the
+//               decimated list of pyramid_class.cpp:301-322).
+//   sector state center[S] (float2), guess[S][6], last_p[S][6], prev_p[S][6],
+//               result[S] (48 B, layout of CorrelationResult), stats[S][4].
+// Everything for an image pair is resident; lk_correlate_all* is one launch per size
+// class (1 / 4 / 8 wavefronts per sector) on one stream.
+#include "lk_device.hpp"
+#include "lk_roi.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+hipError_t lk_launch_solve(const LkSolveArgs &a, int model, int interp, int waves, hipStream_t st);
+hipError_t lk_launch_eval(const LkEvalArgs &a, int model, int interp, hipStream_t st);
+hipError_t lk_launch_solve_only(int n, const float *d_in, float *d_out, hipStream_t st);
+hipError_t lk_launch_sample(int interp, const uint8_t *def, int rows, int cols, const float2 *pts, int n,
+                            float4 *out, hipStream_t st);
+hipError_t lk_launch_pyramid(const uint8_t *src, int srows, int scols, uint8_t *dst, hipStream_t st);
+hipError_t lk_launch_guess(const float2 *center, const float *last_p, float *prev_p, float *guess,
+                           const float *global_guess, float gcx, float gcy, int n_sectors, int model,
+                           int frame, int constant_velocity, hipStream_t st);
+hipError_t lk_launch_warp_points(const float2 *xy, int n, float cx, float cy, int model, const float *d_p,
+                                 float2 *out, hipStream_t st);
+
+namespace {
+
+int n_params_of(int model) {
+  switch (model) {
+  case LK_FM_U: return 1;
+  case LK_FM_UV: return 2;
+  case LK_FM_UVQ: return 3;
+  case LK_FM_UVUXUYVXVY: return 6;
+  default: return -1;
+  }
+}
+
+struct DevImage {
+  uint8_t *lvl[LK_MAX_LEVELS] = {};
+  size_t cap[LK_MAX_LEVELS] = {};
+  int rows = 0, cols = 0;
+  bool valid = false;
+};
+
+struct HostSector {
+  std::vector<float> xy; // level-0 AoS
+  float cx = 0.f, cy = 0.f;
+  bool set = false;
+};
+
+template <class T> struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  hipError_t ensure(size_t want) {
+    if (want <= n && p)
+      return hipSuccess;
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+    hipError_t e = hipMalloc((void **)&p, std::max<size_t>(want, 1) * sizeof(T));
+    if (e == hipSuccess)
+      n = want;
+    return e;
+  }
+  void release() {
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+} // namespace
+
+struct lk_engine {
+  lk_config cfg{};
+  int P = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr, nxt_stream = nullptr;
+  hipEvent_t nxt_done = nullptr, ev_s0 = nullptr, ev_s1 = nullptr, ev_p0 = nullptr, ev_p1 = nullptr;
+  bool nxt_pending = false, solve_timed = false, pyr_timed = false;
+  std::mutex nxt_mu;
+  std::string err;
+
+  DevImage img[3];
+  LkLevelView h_lv[LK_MAX_LEVELS]{};
+  DevBuf<LkLevelView> d_lv;
+  bool lv_dirty = true;
+
+  std::vector<HostSector> hs; // staging until commit
+  bool committed = false;
+  int S = 0;
+  std::vector<uint32_t> h_off[LK_MAX_LEVELS];
+  DevBuf<float2> d_xy[LK_MAX_LEVELS];
+  DevBuf<uint32_t> d_off[LK_MAX_LEVELS];
+  std::vector<float> h_center; // [S][2]
+  DevBuf<float2> d_center;
+  DevBuf<float> d_guess, d_last_p, d_prev_p;
+  DevBuf<lk_result> d_result;
+  DevBuf<uint32_t> d_stats;
+  DevBuf<uint32_t> d_order;
+  std::vector<uint32_t> h_order; // sectors grouped by size class
+  int class_begin[4] = {0, 0, 0, 0};
+  DevBuf<uint32_t> d_single;
+  DevBuf<float> d_scratch; // 64 floats for the stand-alone entry points
+  DevBuf<float2> d_warp;
+  bool stats_valid = false;
+  lk_stats stats{};
+
+  int fail(int code, const std::string &what) {
+    err = what;
+    return code;
+  }
+  int hipfail(hipError_t e, const char *where) {
+    err = std::string(where) + ": " + hipGetErrorString(e);
+    return LK_ERROR_DEVICE;
+  }
+};
+
+#define HIPCHK(call)                                                                                  \
+  do {                                                                                                \
+    hipError_t _e = (call);                                                                           \
+    if (_e != hipSuccess)                                                                             \
+      return e->hipfail(_e, #call);                                                                   \
+  } while (0)
+
+static const int kWavesOfClass[3] = {1, 4, 8};
+static int size_class(int n0) { return n0 <= 2048 ? 0 : (n0 <= 32768 ? 1 : 2); }
+
+extern "C" {
+
+int lk_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+int lk_create(const lk_config *cfg, lk_engine **out) {
+  if (!cfg || !out)
+    return LK_ERROR_BAD_DOMAIN;
+  *out = nullptr;
+  if (n_params_of(cfg->fitting_model) < 0 || cfg->interpolation < 0 || cfg->interpolation > 2)
+    return LK_ERROR_BAD_DOMAIN;
+  if (cfg->py_step < 1 || cfg->py_start < 0 || cfg->py_stop < cfg->py_start ||
+      cfg->py_stop >= LK_MAX_LEVELS || (cfg->py_stop - cfg->py_start) % cfg->py_step != 0)
+    return LK_ERROR_BAD_DOMAIN;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return LK_ERROR_DEVICE; // no silent CPU fallback: the HIP device is the product
+  if (cfg->device < 0 || cfg->device >= ndev)
+    return LK_ERROR_DEVICE;
+  lk_engine *e = new lk_engine();
+  e->cfg = *cfg;
+  e->P = n_params_of(cfg->fitting_model);
+  bool ok = hipSetDevice(cfg->device) == hipSuccess &&
+            hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&e->nxt_stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&e->nxt_done, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreate(&e->ev_s0) == hipSuccess && hipEventCreate(&e->ev_s1) == hipSuccess &&
+            hipEventCreate(&e->ev_p0) == hipSuccess && hipEventCreate(&e->ev_p1) == hipSuccess;
+  if (!ok) {
+    delete e;
+    return LK_ERROR_DEVICE;
+  }
+  e->stream = e->own_stream;
+  *out = e;
+  return LK_ERROR_NONE;
+}
+
+void lk_destroy(lk_engine *e) {
+  if (!e)
+    return;
+  (void)hipSetDevice(e->cfg.device);
+  (void)hipDeviceSynchronize();
+  for (auto &im : e->img)
+    for (auto &p : im.lvl)
+      if (p)
+        (void)hipFree(p);
+  e->d_lv.release();
+  for (int l = 0; l < LK_MAX_LEVELS; ++l) {
+    e->d_xy[l].release();
+    e->d_off[l].release();
+  }
+  e->d_center.release();
+  e->d_guess.release();
+  e->d_last_p.release();
+  e->d_prev_p.release();
+  e->d_result.release();
+  e->d_stats.release();
+  e->d_order.release();
+  e->d_single.release();
+  e->d_scratch.release();
+  e->d_warp.release();
+  if (e->own_stream)
+    (void)hipStreamDestroy(e->own_stream);
+  if (e->nxt_stream)
+    (void)hipStreamDestroy(e->nxt_stream);
+  for (hipEvent_t ev : {e->nxt_done, e->ev_s0, e->ev_s1, e->ev_p0, e->ev_p1})
+    if (ev)
+      (void)hipEventDestroy(ev);
+  delete e;
+}
+
+const char *lk_last_error_string(const lk_engine *e) { return e ? e->err.c_str() : "null engine"; }
+
+int lk_set_stream(lk_engine *e, void *hip_stream) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+  return LK_ERROR_NONE;
+}
+
+int lk_synchronize(lk_engine *e) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipStreamSynchronize(e->nxt_stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return LK_ERROR_NONE;
+}
+
+// ------------------------------------------------------------------------------------
+// images
+// ------------------------------------------------------------------------------------
+static int set_image_common(lk_engine *e, int slot, const void *src, bool src_on_device, int rows,
+                            int cols, int step) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (slot < 0 || slot > 2 || !src || rows < 1 || cols < 1 || step < cols)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_image: bad arguments");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  // the next-frame slot is filled on its own stream so it can overlap a running solve
+  // (manager_class.cpp:1438-1447 / nxtStream in cuda_pyramid.cu:504,557)
+  std::unique_lock<std::mutex> lock(e->nxt_mu, std::defer_lock);
+  hipStream_t st = e->stream;
+  if (slot == LK_IMG_NXT) {
+    lock.lock();
+    st = e->nxt_stream;
+  }
+  DevImage &im = e->img[slot];
+  int r = rows, c = cols;
+  for (int l = 0; l <= e->cfg.py_stop; ++l) {
+    size_t need = (size_t)(r + 2) * (size_t)c + 16;
+    if (need > im.cap[l]) {
+      if (im.lvl[l]) {
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipFree(im.lvl[l]));
+        im.lvl[l] = nullptr;
+      }
+      HIPCHK(hipMalloc((void **)&im.lvl[l], need));
+      im.cap[l] = need;
+    }
+    // guard rows (and the whole level: the pyramid kernel writes every target pixel)
+    HIPCHK(hipMemsetAsync(im.lvl[l] + (size_t)r * (size_t)c, 0, 2 * (size_t)c + 16, st));
+    r /= 2;
+    c /= 2;
+  }
+  HIPCHK(hipMemcpy2DAsync(im.lvl[0], (size_t)cols, src, (size_t)step, (size_t)cols, (size_t)rows,
+                          src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+  const bool timed = slot != LK_IMG_NXT;
+  if (timed)
+    HIPCHK(hipEventRecord(e->ev_p0, st));
+  r = rows;
+  c = cols;
+  for (int l = 1; l <= e->cfg.py_stop; ++l) { // all levels 1..stop (pyramid_class.cpp:92)
+    HIPCHK(lk_launch_pyramid(im.lvl[l - 1], r, c, im.lvl[l], st));
+    r /= 2;
+    c /= 2;
+  }
+  if (timed) {
+    HIPCHK(hipEventRecord(e->ev_p1, st));
+    e->pyr_timed = true;
+  }
+  im.rows = rows;
+  im.cols = cols;
+  im.valid = true;
+  if (slot == LK_IMG_NXT) {
+    HIPCHK(hipEventRecord(e->nxt_done, st));
+    e->nxt_pending = true;
+  } else {
+    e->lv_dirty = true;
+  }
+  if (!src_on_device && slot != LK_IMG_NXT) // pageable host memory: the copy must have left it
+    HIPCHK(hipStreamSynchronize(st));
+  if (!src_on_device && slot == LK_IMG_NXT)
+    HIPCHK(hipStreamSynchronize(st));
+  return LK_ERROR_NONE;
+}
+
+int lk_set_image(lk_engine *e, int slot, const uint8_t *host_pixels, int rows, int cols, int step) {
+  return set_image_common(e, slot, host_pixels, false, rows, cols, step);
+}
+
+int lk_set_image_device(lk_engine *e, int slot, const void *device_pixels, int rows, int cols, int step) {
+  return set_image_common(e, slot, device_pixels, true, rows, cols, step);
+}
+
+static void swap_images(DevImage &a, DevImage &b) { std::swap(a, b); }
+
+int lk_rotate_und_from_def(lk_engine *e) { // pyramid_class.cpp:211-226: def is emptied
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!e->img[LK_IMG_DEF].valid)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_rotate_und_from_def: no deformed image");
+  swap_images(e->img[LK_IMG_UND], e->img[LK_IMG_DEF]);
+  e->img[LK_IMG_DEF].valid = false; // keeps its allocation for reuse
+  e->lv_dirty = true;
+  return LK_ERROR_NONE;
+}
+
+int lk_rotate_def_from_nxt(lk_engine *e) { // pyramid_class.cpp:228-258
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  std::lock_guard<std::mutex> lock(e->nxt_mu);
+  if (!e->img[LK_IMG_NXT].valid)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_rotate_def_from_nxt: no next image");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  if (e->nxt_pending) { // fence: the solve stream must see the finished next pyramid
+    HIPCHK(hipStreamWaitEvent(e->stream, e->nxt_done, 0));
+    e->nxt_pending = false;
+  }
+  swap_images(e->img[LK_IMG_DEF], e->img[LK_IMG_NXT]);
+  e->img[LK_IMG_NXT].valid = false;
+  e->lv_dirty = true;
+  return LK_ERROR_NONE;
+}
+
+int lk_get_pyramid_level(lk_engine *e, int slot, int level, uint8_t *host_out, int *rows, int *cols) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (slot < 0 || slot > 2 || level < 0 || level > e->cfg.py_stop || !e->img[slot].valid)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_pyramid_level: bad slot/level");
+  const DevImage &im = e->img[slot];
+  int r = im.rows >> level, c = im.cols >> level;
+  if (rows)
+    *rows = r;
+  if (cols)
+    *cols = c;
+  if (host_out) {
+    HIPCHK(hipSetDevice(e->cfg.device));
+    hipStream_t st = slot == LK_IMG_NXT ? e->nxt_stream : e->stream;
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpy(host_out, im.lvl[level], (size_t)r * (size_t)c, hipMemcpyDeviceToHost));
+  }
+  return LK_ERROR_NONE;
+}
+
+// ------------------------------------------------------------------------------------
+// sectors
+// ------------------------------------------------------------------------------------
+int lk_clear_sectors(lk_engine *e) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  e->hs.clear();
+  e->committed = false;
+  e->S = 0;
+  return LK_ERROR_NONE;
+}
+
+static HostSector *sector_slot(lk_engine *e, int sector) {
+  if (sector < 0)
+    return nullptr;
+  if ((size_t)sector >= e->hs.size())
+    e->hs.resize((size_t)sector + 1);
+  e->committed = false;
+  return &e->hs[(size_t)sector];
+}
+
+int lk_set_sector_rect(lk_engine *e, int sector, int x0, int y0, int x1, int y1) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  HostSector *s = sector_slot(e, sector);
+  if (!s || x1 < x0 || y1 < y0)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sector_rect: bad rectangle");
+  s->xy.clear();
+  s->xy.reserve(2 * (size_t)(x1 - x0 + 1) * (size_t)(y1 - y0 + 1));
+  lkroi::rect_points(x0, y0, x1, y1, s->xy);
+  s->cx = (float)(x0 + x1) * 0.5f;
+  s->cy = (float)(y0 + y1) * 0.5f;
+  s->set = true;
+  return LK_ERROR_NONE;
+}
+
+int lk_set_rect_grid(lk_engine *e, float x_begin, float y_begin, float x_end, float y_end, int hs, int vs,
+                     int first, int count) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (hs < 1 || vs < 1)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_rect_grid: subdivisions must be >= 1");
+  const int total = hs * vs;
+  if (count < 0)
+    count = total - first;
+  if (first < 0 || count < 0 || first + count > total)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_rect_grid: sector range outside the grid");
+  lkroi::RectGrid g = lkroi::rect_grid(x_begin, y_begin, x_end, y_end, hs, vs);
+  if (g.xdim < 0 || g.ydim < 0)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_rect_grid: domain smaller than the grid");
+  e->hs.clear();
+  e->hs.resize((size_t)count);
+  e->committed = false;
+  for (int k = 0; k < count; ++k) {
+    int iSector = first + k, i = iSector / vs, j = iSector % vs; // iSector = i*vs + j
+    HostSector &s = e->hs[(size_t)k];
+    int cx = g.cx[i], cy = g.cy[j];
+    s.xy.reserve(2 * (size_t)(2 * g.xdim + 1) * (size_t)(2 * g.ydim + 1));
+    lkroi::rect_points(cx - g.xdim, cy - g.ydim, cx + g.xdim, cy + g.ydim, s.xy);
+    s.cx = (float)cx; // manager_class.cpp:438-441 passes the integer centre
+    s.cy = (float)cy;
+    s.set = true;
+  }
+  return LK_ERROR_NONE;
+}
+
+int lk_set_sector_annular(lk_engine *e, int sector, float r, float dr, float a, float da, float cx, float cy,
+                          int as) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  HostSector *s = sector_slot(e, sector);
+  if (!s)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sector_annular: bad sector index");
+  s->xy.clear();
+  if (!lkroi::annular_points(r, dr, a, da, cx, cy, as, s->xy) || s->xy.empty())
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sector_annular: empty sector");
+  lkroi::mean_center(s->xy.data(), (int)(s->xy.size() / 2), s->cx, s->cy); // correlation_class.cpp:337-339
+  s->set = true;
+  return LK_ERROR_NONE;
+}
+
+int lk_set_sector_blob(lk_engine *e, int sector, const float *contour_xy, int n_vertices) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  HostSector *s = sector_slot(e, sector);
+  if (!s || !contour_xy)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sector_blob: bad arguments");
+  s->xy.clear();
+  if (!lkroi::BlobPolygon::inside_points(contour_xy, n_vertices, s->xy) || s->xy.empty()) {
+    s->set = false;
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sector_blob: contour is not a simple polygon");
+  }
+  lkroi::mean_center(s->xy.data(), (int)(s->xy.size() / 2), s->cx, s->cy);
+  s->set = true;
+  return LK_ERROR_NONE;
+}
+
+int lk_set_sector_points(lk_engine *e, int sector, const float *xy, int n, int use_center, float cx,
+                         float cy) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  HostSector *s = sector_slot(e, sector);
+  if (!s || !xy || n < 1)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sector_points: bad arguments");
+  s->xy.assign(xy, xy + 2 * (size_t)n);
+  if (use_center) {
+    s->cx = cx;
+    s->cy = cy;
+  } else {
+    lkroi::mean_center(xy, n, s->cx, s->cy);
+  }
+  s->set = true;
+  return LK_ERROR_NONE;
+}
+
+int lk_commit_sectors(lk_engine *e) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  const int S = (int)e->hs.size();
+  if (S == 0)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_commit_sectors: no sectors");
+  for (int s = 0; s < S; ++s)
+    if (!e->hs[(size_t)s].set)
+      return e->fail(LK_ERROR_BAD_DOMAIN, "lk_commit_sectors: sector " + std::to_string(s) + " was never set");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const lk_config &cfg = e->cfg;
+  const int first = cfg.py_start == 0 ? cfg.py_step : cfg.py_start; // pyramid_class.cpp:299
+  // level lists: level 0 always; first, first+step, ... <= stop, each from the previous
+  std::vector<int> levels{0};
+  for (int l = first; l <= cfg.py_stop; l += cfg.py_step)
+    levels.push_back(l);
+  std::vector<std::vector<float>> cat(LK_MAX_LEVELS);
+  for (int l = 0; l < LK_MAX_LEVELS; ++l)
+    e->h_off[l].assign(1, 0u);
+  size_t total0 = 0;
+  for (int s = 0; s < S; ++s)
+    total0 += e->hs[(size_t)s].xy.size();
+  if (total0 / 2 >= 0xffffffffull)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_commit_sectors: more than 2^32 samples");
+  cat[0].reserve(total0);
+  e->h_center.resize(2 * (size_t)S);
+  std::vector<float> prev, cur;
+  for (int s = 0; s < S; ++s) {
+    const HostSector &hs = e->hs[(size_t)s];
+    e->h_center[2 * (size_t)s] = hs.cx;
+    e->h_center[2 * (size_t)s + 1] = hs.cy;
+    cat[0].insert(cat[0].end(), hs.xy.begin(), hs.xy.end());
+    e->h_off[0].push_back((uint32_t)(cat[0].size() / 2));
+    const float *pxy = hs.xy.data();
+    int pn = (int)(hs.xy.size() / 2), plevel = 0;
+    for (size_t li = 1; li < levels.size(); ++li) {
+      int l = levels[li];
+      cur.clear();
+      int kept = lkroi::decimate(pxy, pn, l - plevel, cur);
+      cat[l].insert(cat[l].end(), cur.begin(), cur.end());
+      e->h_off[l].push_back((uint32_t)(cat[l].size() / 2));
+      prev.swap(cur);
+      pxy = prev.data();
+      pn = kept;
+      plevel = l;
+    }
+  }
+  for (int l : levels) {
+    HIPCHK(e->d_xy[l].ensure(cat[l].size() / 2 + 1));
+    HIPCHK(e->d_off[l].ensure((size_t)S + 1));
+    if (!cat[l].empty())
+      HIPCHK(hipMemcpy(e->d_xy[l].p, cat[l].data(), cat[l].size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_off[l].p, e->h_off[l].data(), ((size_t)S + 1) * sizeof(uint32_t),
+                     hipMemcpyHostToDevice));
+  }
+  HIPCHK(e->d_center.ensure((size_t)S));
+  HIPCHK(hipMemcpy(e->d_center.p, e->h_center.data(), 2 * (size_t)S * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(e->d_guess.ensure(6 * (size_t)S));
+  HIPCHK(e->d_last_p.ensure(6 * (size_t)S));
+  HIPCHK(e->d_prev_p.ensure(6 * (size_t)S));
+  HIPCHK(e->d_result.ensure((size_t)S));
+  HIPCHK(e->d_stats.ensure(4 * (size_t)S));
+  HIPCHK(hipMemset(e->d_guess.p, 0, 6 * (size_t)S * sizeof(float)));
+  HIPCHK(hipMemset(e->d_last_p.p, 0, 6 * (size_t)S * sizeof(float)));
+  HIPCHK(hipMemset(e->d_prev_p.p, 0, 6 * (size_t)S * sizeof(float)));
+  HIPCHK(hipMemset(e->d_stats.p, 0, 4 * (size_t)S * sizeof(uint32_t)));
+  // size classes -> wavefronts per sector
+  e->h_order.clear();
+  e->h_order.reserve((size_t)S);
+  for (int c = 0; c < 3; ++c) {
+    e->class_begin[c] = (int)e->h_order.size();
+    for (int s = 0; s < S; ++s)
+      if (size_class((int)(e->hs[(size_t)s].xy.size() / 2)) == c)
+        e->h_order.push_back((uint32_t)s);
+  }
+  e->class_begin[3] = (int)e->h_order.size();
+  HIPCHK(e->d_order.ensure((size_t)S));
+  HIPCHK(hipMemcpy(e->d_order.p, e->h_order.data(), (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIPCHK(e->d_single.ensure(1));
+  HIPCHK(e->d_scratch.ensure(64));
+  e->S = S;
+  e->committed = true;
+  e->lv_dirty = true;
+  e->stats_valid = false;
+  return LK_ERROR_NONE;
+}
+
+int lk_sector_count(const lk_engine *e) { return e ? (e->committed ? e->S : (int)e->hs.size()) : 0; }
+
+int lk_get_sector_info(lk_engine *e, int sector, int *n_points, float *cx, float *cy) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (sector < 0 || (size_t)sector >= e->hs.size() || !e->hs[(size_t)sector].set)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_sector_info: unknown sector");
+  const HostSector &s = e->hs[(size_t)sector];
+  if (n_points)
+    *n_points = (int)(s.xy.size() / 2);
+  if (cx)
+    *cx = s.cx;
+  if (cy)
+    *cy = s.cy;
+  return LK_ERROR_NONE;
+}
+
+int lk_get_sector_level_count(lk_engine *e, int sector, int level, int *n) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!e->committed || sector < 0 || sector >= e->S || level < 0 || level >= LK_MAX_LEVELS ||
+      e->h_off[level].size() != (size_t)e->S + 1)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_sector_level_count: unknown sector/level");
+  if (n)
+    *n = (int)(e->h_off[level][(size_t)sector + 1] - e->h_off[level][(size_t)sector]);
+  return LK_ERROR_NONE;
+}
+
+int lk_get_und_xy(lk_engine *e, int sector, float *xy, int cap, int *count) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (sector < 0 || (size_t)sector >= e->hs.size() || !e->hs[(size_t)sector].set)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_und_xy: unknown sector");
+  const HostSector &s = e->hs[(size_t)sector];
+  int n = (int)(s.xy.size() / 2);
+  if (count)
+    *count = n;
+  if (xy && cap > 0)
+    std::memcpy(xy, s.xy.data(), 2 * sizeof(float) * (size_t)std::min(n, cap));
+  return LK_ERROR_NONE;
+}
+
+int lk_get_def_xy(lk_engine *e, int sector, const float *p, float *xy, int cap, int *count) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!e->committed || sector < 0 || sector >= e->S || !p)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_def_xy: unknown sector");
+  const uint32_t off = e->h_off[0][(size_t)sector];
+  const int n = (int)(e->h_off[0][(size_t)sector + 1] - off);
+  if (count)
+    *count = n;
+  if (!xy || cap <= 0)
+    return LK_ERROR_NONE;
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(e->d_warp.ensure((size_t)n));
+  float pp[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < e->P; ++i)
+    pp[i] = p[i];
+  HIPCHK(hipMemcpyAsync(e->d_scratch.p, pp, sizeof(pp), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(lk_launch_warp_points(e->d_xy[0].p + off, n, e->h_center[2 * (size_t)sector],
+                               e->h_center[2 * (size_t)sector + 1], e->cfg.fitting_model, e->d_scratch.p,
+                               e->d_warp.p, e->stream));
+  HIPCHK(hipMemcpyAsync(xy, e->d_warp.p, 2 * sizeof(float) * (size_t)std::min(n, cap),
+                        hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return LK_ERROR_NONE;
+}
+
+// ------------------------------------------------------------------------------------
+// solve
+// ------------------------------------------------------------------------------------
+static int refresh_level_views(lk_engine *e) {
+  if (!e->committed)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "sectors are not committed (call lk_commit_sectors)");
+  const DevImage &u = e->img[LK_IMG_UND], &d = e->img[LK_IMG_DEF];
+  if (!u.valid || !d.valid)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "undeformed and deformed images must be set before correlating");
+  if (!e->lv_dirty)
+    return LK_ERROR_NONE;
+  // every level-0 sample must lie inside the undeformed image
+  for (int l = 0; l < LK_MAX_LEVELS; ++l) {
+    LkLevelView &v = e->h_lv[l];
+    std::memset(&v, 0, sizeof(v));
+    if (l > e->cfg.py_stop)
+      continue;
+    v.und = u.lvl[l];
+    v.def = d.lvl[l];
+    v.xy = e->d_xy[l].p;
+    v.off = e->d_off[l].p;
+    v.urows = u.rows >> l;
+    v.ucols = u.cols >> l;
+    v.drows = d.rows >> l;
+    v.dcols = d.cols >> l;
+  }
+  HIPCHK(e->d_lv.ensure(LK_MAX_LEVELS));
+  HIPCHK(hipMemcpyAsync(e->d_lv.p, e->h_lv, sizeof(e->h_lv), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream)); // h_lv is pageable
+  e->lv_dirty = false;
+  return LK_ERROR_NONE;
+}
+
+static LkSolveArgs base_args(lk_engine *e, const float *d_guess, lk_result *d_result) {
+  LkSolveArgs a{};
+  a.lv = e->d_lv.p;
+  a.center = e->d_center.p;
+  a.guess = d_guess;
+  a.result = d_result;
+  a.last_p = e->d_last_p.p;
+  a.stats = e->d_stats.p;
+  a.py_start = e->cfg.py_start;
+  a.py_step = e->cfg.py_step;
+  a.py_stop = e->cfg.py_stop;
+  a.precision = e->cfg.precision;
+  a.max_iters = e->cfg.max_iters;
+  return a;
+}
+
+static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
+  HIPCHK(hipEventRecord(e->ev_s0, e->stream));
+  for (int c = 0; c < 3; ++c) {
+    int n = e->class_begin[c + 1] - e->class_begin[c];
+    if (n <= 0)
+      continue;
+    LkSolveArgs a = base_args(e, d_guess, d_result);
+    a.order = e->d_order.p + e->class_begin[c];
+    a.n_sectors = n;
+    a.chunk = (n + 7) / 8;
+    HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, kWavesOfClass[c], e->stream));
+  }
+  HIPCHK(hipEventRecord(e->ev_s1, e->stream));
+  e->solve_timed = true;
+  e->stats_valid = false;
+  return LK_ERROR_NONE;
+}
+
+int lk_correlate_all_device(lk_engine *e, const void *d_guesses, void *d_results) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!d_results)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_correlate_all_device: null result buffer");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  int rc = refresh_level_views(e);
+  if (rc)
+    return rc;
+  return launch_all(e, d_guesses ? (const float *)d_guesses : e->d_guess.p, (lk_result *)d_results);
+}
+
+int lk_correlate_all(lk_engine *e, const float *guesses, lk_result *out) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!out)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_correlate_all: null result buffer");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  int rc = refresh_level_views(e);
+  if (rc)
+    return rc;
+  if (guesses)
+    HIPCHK(hipMemcpyAsync(e->d_guess.p, guesses, 6 * (size_t)e->S * sizeof(float), hipMemcpyHostToDevice,
+                          e->stream));
+  rc = launch_all(e, e->d_guess.p, e->d_result.p);
+  if (rc)
+    return rc;
+  HIPCHK(hipMemcpyAsync(out, e->d_result.p, (size_t)e->S * sizeof(lk_result), hipMemcpyDeviceToHost,
+                        e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return LK_ERROR_NONE;
+}
+
+int lk_correlate(lk_engine *e, int sector, float *guess_inout, lk_result *out) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!guess_inout || !out)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_correlate: null argument");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  int rc = refresh_level_views(e);
+  if (rc)
+    return rc;
+  if (sector < 0 || sector >= e->S)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_correlate: unknown sector");
+  float g[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < e->P; ++i)
+    g[i] = guess_inout[i];
+  uint32_t sidx = (uint32_t)sector;
+  HIPCHK(hipMemcpyAsync(e->d_guess.p + 6 * (size_t)sector, g, sizeof(g), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->d_single.p, &sidx, sizeof(sidx), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  LkSolveArgs a = base_args(e, e->d_guess.p, e->d_result.p);
+  a.order = e->d_single.p;
+  a.n_sectors = 1;
+  a.chunk = 1;
+  int n0 = (int)(e->h_off[0][(size_t)sector + 1] - e->h_off[0][(size_t)sector]);
+  HIPCHK(hipEventRecord(e->ev_s0, e->stream));
+  HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, kWavesOfClass[size_class(n0)],
+                         e->stream));
+  HIPCHK(hipEventRecord(e->ev_s1, e->stream));
+  e->solve_timed = true;
+  e->stats_valid = false;
+  HIPCHK(hipMemcpyAsync(out, e->d_result.p + sector, sizeof(lk_result), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (int i = 0; i < e->P; ++i)
+    guess_inout[i] = out->resultingParameters[i]; // cuda_class.cu:289-290
+  return LK_ERROR_NONE;
+}
+
+int lk_adjust_initial_guess(lk_engine *e, int frame, int constant_velocity, const float *global_guess,
+                            float global_cx, float global_cy) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!e->committed)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_adjust_initial_guess: sectors are not committed");
+  float gg[6] = {0, 0, 0, 0, 0, 0};
+  if (global_guess)
+    for (int i = 0; i < 6; ++i)
+      gg[i] = global_guess[i];
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(lk_launch_guess(e->d_center.p, e->d_last_p.p, e->d_prev_p.p, e->d_guess.p, gg, global_cx, global_cy,
+                         e->S, e->cfg.fitting_model, frame, constant_velocity, e->stream));
+  return LK_ERROR_NONE;
+}
+
+int lk_get_guesses(lk_engine *e, float *guesses) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!e->committed || !guesses)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_guesses: sectors are not committed");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipMemcpyAsync(guesses, e->d_guess.p, 6 * (size_t)e->S * sizeof(float), hipMemcpyDeviceToHost,
+                        e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return LK_ERROR_NONE;
+}
+
+int lk_evaluate(lk_engine *e, int sector, int level, const float *p, float *A36, float *b6, float *chi,
+                int *error) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  HIPCHK(hipSetDevice(e->cfg.device));
+  int rc = refresh_level_views(e);
+  if (rc)
+    return rc;
+  if (sector < 0 || sector >= e->S || level < 0 || level > e->cfg.py_stop || !p ||
+      e->h_off[level].size() != (size_t)e->S + 1)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_evaluate: unknown sector/level");
+  LkEvalArgs a{};
+  a.lv = e->d_lv.p;
+  a.center = e->d_center.p;
+  a.sector = sector;
+  a.level = level;
+  for (int i = 0; i < 6; ++i)
+    a.p[i] = i < e->P ? p[i] : 0.f;
+  a.out = e->d_scratch.p;
+  HIPCHK(lk_launch_eval(a, e->cfg.fitting_model, e->cfg.interpolation, e->stream));
+  float h[44];
+  HIPCHK(hipMemcpyAsync(h, e->d_scratch.p, sizeof(h), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (A36)
+    std::memcpy(A36, h, 36 * sizeof(float));
+  if (b6)
+    std::memcpy(b6, h + 36, 6 * sizeof(float));
+  if (chi)
+    *chi = h[42];
+  if (error)
+    *error = h[43] != 0.f ? LK_ERROR_INTERPOLATION_OUT_OF_IMAGE : LK_ERROR_NONE;
+  return LK_ERROR_NONE;
+}
+
+int lk_sample(lk_engine *e, int slot, int level, const float *xy, int n, float *out4) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (slot < 0 || slot > 2 || level < 0 || level > e->cfg.py_stop || !e->img[slot].valid || !xy || !out4 ||
+      n < 1)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_sample: bad arguments");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const DevImage &im = e->img[slot];
+  DevBuf<float2> d_pts;
+  DevBuf<float4> d_out;
+  HIPCHK(d_pts.ensure((size_t)n));
+  HIPCHK(d_out.ensure((size_t)n));
+  int rc = LK_ERROR_NONE;
+  hipError_t he = hipMemcpyAsync(d_pts.p, xy, 2 * sizeof(float) * (size_t)n, hipMemcpyHostToDevice, e->stream);
+  if (he == hipSuccess)
+    he = lk_launch_sample(e->cfg.interpolation, im.lvl[level], im.rows >> level, im.cols >> level, d_pts.p, n,
+                          d_out.p, e->stream);
+  if (he == hipSuccess)
+    he = hipMemcpyAsync(out4, d_out.p, 4 * sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, e->stream);
+  if (he == hipSuccess)
+    he = hipStreamSynchronize(e->stream);
+  if (he != hipSuccess)
+    rc = e->hipfail(he, "lk_sample");
+  d_pts.release();
+  d_out.release();
+  return rc;
+}
+
+int lk_damped_solve(lk_engine *e, int n, const float *A, const float *b, float lambda, float scaling,
+                    float *dp) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!(n == 1 || n == 2 || n == 3 || n == 6) || !A || !b || !dp)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_damped_solve: n must be 1, 2, 3 or 6");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(e->d_scratch.ensure(64));
+  float h[44];
+  std::memset(h, 0, sizeof(h));
+  for (int i = 0; i < n; ++i) {
+    h[36 + i] = b[i];
+    for (int j = 0; j < n; ++j)
+      h[i * 6 + j] = A[i * n + j];
+  }
+  h[42] = lambda;
+  h[43] = scaling;
+  HIPCHK(hipMemcpyAsync(e->d_scratch.p, h, sizeof(h), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(lk_launch_solve_only(n, e->d_scratch.p, e->d_scratch.p + 48, e->stream));
+  float o[6];
+  HIPCHK(hipMemcpyAsync(o, e->d_scratch.p + 48, sizeof(o), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (int i = 0; i < n; ++i)
+    dp[i] = o[i];
+  return LK_ERROR_NONE;
+}
+
+int lk_get_stats(lk_engine *e, lk_stats *out) {
+  if (!e || !out)
+    return LK_ERROR_BAD_DOMAIN;
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (!e->stats_valid && e->committed) {
+    std::vector<uint32_t> h(4 * (size_t)e->S);
+    HIPCHK(hipMemcpy(h.data(), e->d_stats.p, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    lk_stats s{};
+    s.sectors = (uint64_t)e->S;
+    for (int i = 0; i < e->S; ++i) {
+      s.evaluations += h[4 * (size_t)i];
+      s.sample_evaluations += h[4 * (size_t)i + 1];
+      s.point_iterations += h[4 * (size_t)i + 2];
+    }
+    // 25 B per sample-evaluation + 196 B per evaluation
+    s.algorithmic_bytes = 25ull * s.sample_evaluations + 196ull * s.evaluations;
+    s.solve_ms = e->stats.solve_ms;
+    s.pyramid_ms = e->stats.pyramid_ms;
+    e->stats = s;
+    e->stats_valid = true;
+  }
+  if (e->solve_timed) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e->ev_s0, e->ev_s1) == hipSuccess)
+      e->stats.solve_ms = ms;
+  }
+  if (e->pyr_timed) {
+    float ms = 0.f;
+    if (hipEventSynchronize(e->ev_p1) == hipSuccess && hipEventElapsedTime(&ms, e->ev_p0, e->ev_p1) == hipSuccess)
+      e->stats.pyramid_ms = ms;
+  }
+  *out = e->stats;
+  return LK_ERROR_NONE;
+}
+
+} // extern "C"

@@ -1,0 +1,974 @@
+// lk_kernels.hip - hand-written CDNA4 (gfx950) kernels of the Lucas-Kanade engine.
+//
+//   lk_solve_kernel    one workgroup (1, 4 or 8 wavefronts) owns one sector for its
+//                      whole coarse-to-fine Levenberg-Marquardt solve: warp -> bicubic
+//                      sample of the deformed image + gradient -> residual -> per-lane
+//                      accumulation of the 21+6+1 sums -> DPP wavefront reduction ->
+//                      6x6 pivoted-QR solve in registers -> accept/reject on the device.
+//                      Replaces kCorrelation + k_global_reduction +
+//                      k_build_LS_problem_in_GPU0 + cuSOLVER potrf/potrs + kScale +
+//                      kUpdateParameters and the host loop of CudaClass::correlate
+//                      (cuda_class.cu:104-473, correlationKernel.cu, kernels.cu:12-103,
+//                      cuda_solver.cu), following the CPU engine's semantics
+//                      (correlation_class.cpp:349-640).
+//   lk_pyramid_kernel  5x5 Gaussian /2 level build with the CPU engine's arithmetic
+//                      (pyramid_class.cpp:83-122); replaces k_pyramid_bw (kernels.cu:761).
+//   small utilities    initial-guess policy, sample warping, stand-alone evaluation/solve.
+//
+// This translation unit is compiled with -ffp-contract=off: the reference's x86-64 builds
+// have no FMA, and per-sample values (warp, bicubic value/gradient, residual, H) are kept
+// bit-identical to that arithmetic.  FMAs appear only where they are provably exact
+// (the bicubic coefficient build, see bicubic_coeffs) or where only the summation order
+// already differs from the reference (the A/b/chi accumulators).
+#include "lk_device.hpp"
+
+#include <float.h>
+
+namespace {
+
+constexpr int kWave = 64;
+
+__host__ __device__ constexpr int n_params(int model) {
+  return model == LK_FM_U ? 1 : model == LK_FM_UV ? 2 : model == LK_FM_UVQ ? 3 : 6;
+}
+
+// ------------------------------------------------------------------------------------
+// wavefront reduction: 4 DPP steps inside each row of 16 lanes, then 4 readlanes.
+// Every lane ends with the same bits (the tree is identical for all lanes).
+// ------------------------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+  int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
+  return v + __int_as_float(t);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+  v = dpp_add<0xB1>(v);  // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);  // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v); // row_half_mirror
+  v = dpp_add<0x140>(v); // row_mirror
+  float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
+
+__device__ __forceinline__ float ub0(uint32_t v) { return (float)(v & 0xffu); }
+__device__ __forceinline__ float ub1(uint32_t v) { return (float)((v >> 8) & 0xffu); }
+__device__ __forceinline__ float ub2(uint32_t v) { return (float)((v >> 16) & 0xffu); }
+__device__ __forceinline__ float ub3(uint32_t v) { return (float)(v >> 24); }
+
+// ------------------------------------------------------------------------------------
+// bicubic (interpolation_class.cpp:79-138, :243-336)
+// ------------------------------------------------------------------------------------
+// The reference builds, per deformed pixel, a 16-vector of values and central differences
+// and multiplies it by a 16x16 integer matrix (:296-333).  That map factors as
+//     a[jk][ik] = sum_r sum_c Cm[jk][r] * Cm[ik][c] * Pix[r][c]
+// with Pix the 4x4 u8 window (rows iy-1..iy+2, cols ix-1..ix+2) and Cm the 1-D
+// "4 pixels -> monomial coefficients on [1,2]" matrix below.  Every product and every
+// partial sum is a multiple of 1/4 below 2^24/4 in magnitude, hence exactly representable
+// in float32: the factored form, in any order and with FMAs, yields the reference's
+// coefficients bit for bit (tests/test_parity_gpu.py::test_bicubic_coefficients_exact).
+__device__ __forceinline__ void cubic_1d(float p0, float p1, float p2, float p3, float &c0,
+                                         float &c1, float &c2, float &c3) {
+  c0 = __builtin_fmaf(2.0f, p0, __builtin_fmaf(-3.0f, p1, __builtin_fmaf(3.0f, p2, -p3)));
+  c1 = __builtin_fmaf(-4.0f, p0, __builtin_fmaf(9.5f, p1, __builtin_fmaf(-8.0f, p2, 2.5f * p3)));
+  c2 = __builtin_fmaf(2.5f, p0, __builtin_fmaf(-7.0f, p1, __builtin_fmaf(6.5f, p2, -2.0f * p3)));
+  c3 = __builtin_fmaf(-0.5f, p0, __builtin_fmaf(1.5f, p1, __builtin_fmaf(-1.5f, p2, 0.5f * p3)));
+}
+
+// a[4*jk+ik]; def points at the level's image, pitch = cols
+__device__ __forceinline__ void bicubic_coeffs(const uint8_t *def, int cols, int ix, int iy,
+                                               float (&a)[16]) {
+  const uint8_t *base = def + (size_t)(iy - 1) * (size_t)cols + (size_t)(ix - 1);
+  uint32_t r0 = load_u32_unaligned(base);
+  uint32_t r1 = load_u32_unaligned(base + cols);
+  uint32_t r2 = load_u32_unaligned(base + 2 * (size_t)cols);
+  uint32_t r3 = load_u32_unaligned(base + 3 * (size_t)cols);
+  // t[r][k]: x-direction transform of image row r
+  float t0[4], t1[4], t2[4], t3[4];
+  cubic_1d(ub0(r0), ub1(r0), ub2(r0), ub3(r0), t0[0], t0[1], t0[2], t0[3]);
+  cubic_1d(ub0(r1), ub1(r1), ub2(r1), ub3(r1), t1[0], t1[1], t1[2], t1[3]);
+  cubic_1d(ub0(r2), ub1(r2), ub2(r2), ub3(r2), t2[0], t2[1], t2[2], t2[3]);
+  cubic_1d(ub0(r3), ub1(r3), ub2(r3), ub3(r3), t3[0], t3[1], t3[2], t3[3]);
+#pragma unroll
+  for (int ik = 0; ik < 4; ++ik) // y-direction transform of column ik
+    cubic_1d(t0[ik], t1[ik], t2[ik], t3[ik], a[0 + ik], a[4 + ik], a[8 + ik], a[12 + ik]);
+}
+
+// W, dW/dx, dW/dy with the reference's monomial evaluation order (:94-126): three
+// running sums, jk outer / ik inner, each term built left to right.
+__device__ __forceinline__ void bicubic_eval(const float (&a)[16], float dx, float dy, float &W,
+                                             float &Wx, float &Wy) {
+  float px[4] = {1.f, dx, dx * dx, dx * dx * dx};
+  float py[4] = {1.f, dy, dy * dy, dy * dy * dy};
+  W = 0.f;
+  Wx = 0.f;
+  Wy = 0.f;
+#pragma unroll
+  for (int jk = 0; jk < 4; ++jk) {
+#pragma unroll
+    for (int ik = 0; ik < 4; ++ik) {
+      float c = a[jk * 4 + ik];
+      W += c * py[jk] * px[ik];
+      if (ik > 0)
+        Wx += (float)ik * c * py[jk] * px[ik - 1];
+      if (jk > 0)
+        Wy += (float)jk * c * py[jk - 1] * px[ik];
+    }
+  }
+}
+
+// returns false when the sample leaves the image (error_interpolation_out_of_image)
+template <int INTERP>
+__device__ __forceinline__ bool sample_def(const uint8_t *def, int rows, int cols, float xd,
+                                           float yd, float &W, float &Wx, float &Wy) {
+  if constexpr (INTERP == LK_IM_BICUBIC) {
+    if (!(xd > 1.f && yd > 1.f && xd < (float)cols - 2.f && yd < (float)rows - 2.f))
+      return false;
+    int ix = (int)xd, iy = (int)yd;
+    float a[16];
+    bicubic_coeffs(def, cols, ix, iy, a);
+    float dx = xd - (float)ix + 1.f, dy = yd - (float)iy + 1.f;
+    bicubic_eval(a, dx, dy, W, Wx, Wy);
+    return true;
+  } else if constexpr (INTERP == LK_IM_BILINEAR) { // :140-195, :338-374
+    if (!(xd > 0.f && yd > 0.f && xd < (float)(cols - 1) && yd < (float)(rows - 1)))
+      return false;
+    int ix = (int)xd, iy = (int)yd;
+    const uint8_t *q = def + (size_t)iy * (size_t)cols + (size_t)ix;
+    float w00 = (float)q[0], w10 = (float)q[1], w01 = (float)q[cols], w11 = (float)q[cols + 1];
+    float a0 = w00, a1 = w10 - w00, a2 = w01 - w00, a3 = w11 - w10 - w01 + w00;
+    float dx = xd - (float)ix, dy = yd - (float)iy;
+    // jk outer / ik inner with px = {1,dx}, py = {1,dy}
+    W = 0.f + a0;
+    W += a1 * dx;
+    Wx = 0.f + a1;
+    W += a2 * dy;
+    Wy = 0.f + a2;
+    W += a3 * dy * dx;
+    Wx += a3 * dy;
+    Wy += a3 * dx;
+    return true;
+  } else { // nearest :197-226, :376-406
+    if (!(xd > 0.f && yd > 0.f && xd < (float)(cols - 1) && yd < (float)(rows - 1)))
+      return false;
+    int ix = (int)(xd + 0.5f), iy = (int)(yd + 0.5f);
+    const uint8_t *q = def + (size_t)iy * (size_t)cols + (size_t)ix;
+    float w00 = (float)q[0], w10 = (float)q[1], w01 = (float)q[cols];
+    W = w00;
+    Wx = w10 - w00;
+    Wy = w01 - w00;
+    return true;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// per-sample body: warp (model_class.cpp:48-202), sample, residual, H
+// (interpolation_class.cpp:701-739).  H = dW/dx * dTx/dp + dW/dy * dTy/dp with the zero
+// entries of dT/dp dropped (x*1 + y*0 == x exactly for finite y).
+// ------------------------------------------------------------------------------------
+template <int MODEL> struct Warp;
+template <> struct Warp<LK_FM_U> {
+  static __device__ __forceinline__ void apply(float x, float y, float, float, const float *p,
+                                               float &xd, float &yd, float &, float &) {
+    xd = x + p[0];
+    yd = y;
+  }
+  static __device__ __forceinline__ void jac(float Wx, float, float, float, float *H) { H[0] = Wx; }
+};
+template <> struct Warp<LK_FM_UV> {
+  static __device__ __forceinline__ void apply(float x, float y, float, float, const float *p,
+                                               float &xd, float &yd, float &, float &) {
+    xd = x + p[0];
+    yd = y + p[1];
+  }
+  static __device__ __forceinline__ void jac(float Wx, float Wy, float, float, float *H) {
+    H[0] = Wx;
+    H[1] = Wy;
+  }
+};
+template <> struct Warp<LK_FM_UVQ> {
+  static __device__ __forceinline__ void apply(float x, float y, float cx, float cy,
+                                               const float *p, float &xd, float &yd, float &dx,
+                                               float &dy) {
+    dx = x - cx;
+    dy = y - cy;
+    xd = x + p[0] - p[2] * dy;
+    yd = y + p[1] + p[2] * dx;
+  }
+  static __device__ __forceinline__ void jac(float Wx, float Wy, float dx, float dy, float *H) {
+    H[0] = Wx;
+    H[1] = Wy;
+    H[2] = Wx * (-dy) + Wy * dx;
+  }
+};
+template <> struct Warp<LK_FM_UVUXUYVXVY> {
+  static __device__ __forceinline__ void apply(float x, float y, float cx, float cy,
+                                               const float *p, float &xd, float &yd, float &dx,
+                                               float &dy) {
+    dx = x - cx;
+    dy = y - cy;
+    xd = x + p[0] + p[2] * dx + p[3] * dy;
+    yd = y + p[1] + p[4] * dx + p[5] * dy;
+  }
+  static __device__ __forceinline__ void jac(float Wx, float Wy, float dx, float dy, float *H) {
+    H[0] = Wx;
+    H[1] = Wy;
+    H[2] = Wx * dx;
+    H[3] = Wx * dy;
+    H[4] = Wy * dx;
+    H[5] = Wy * dy;
+  }
+};
+
+template <int P> struct Sums { // upper triangle row-major, then b, then chi
+  static constexpr int NA = P * (P + 1) / 2;
+  static constexpr int N = NA + P + 1;
+  float v[N];
+};
+
+// One evaluation of one sector at one level by the whole workgroup
+// (apply_model_and_interpolate, correlation_class.cpp:131-300).  On return every thread
+// holds the same totals; returns the error flag (any sample out of the image).
+template <int MODEL, int INTERP, int WAVES>
+__device__ __forceinline__ bool evaluate(const LkLevelView &lv, uint32_t off, int n, float cx,
+                                         float cy, const float (&p)[6], Sums<n_params(MODEL)> &S,
+                                         float *lds) {
+  constexpr int P = n_params(MODEL);
+  using SumsT = Sums<P>;
+  constexpr int T = WAVES * kWave;
+#pragma unroll
+  for (int i = 0; i < SumsT::N; ++i)
+    S.v[i] = 0.f;
+  bool bad = false;
+  const float2 *xy = lv.xy + off;
+  const int ucols = lv.ucols, umaxr = lv.urows - 1, umaxc = lv.ucols - 1;
+  for (int k = (int)threadIdx.x; k < n; k += T) {
+    float2 q = xy[k];
+    float xd, yd, dx = 0.f, dy = 0.f;
+    Warp<MODEL>::apply(q.x, q.y, cx, cy, p, xd, yd, dx, dy);
+    int uix = (int)(q.x + 0.5f), uiy = (int)(q.y + 0.5f);
+    uix = min(max(uix, 0), umaxc); // memory safety only; valid sample lists never clamp
+    uiy = min(max(uiy, 0), umaxr);
+    float und_w = (float)lv.und[(size_t)uiy * (size_t)ucols + (size_t)uix];
+    float W, Wx, Wy;
+    if (!sample_def<INTERP>(lv.def, lv.drows, lv.dcols, xd, yd, W, Wx, Wy)) {
+      bad = true;
+      continue; // the sums of an evaluation that hit the error are never used
+    }
+    float V = und_w - W;
+    float H[P];
+    Warp<MODEL>::jac(Wx, Wy, dx, dy, H);
+    int idx = 0;
+#pragma unroll
+    for (int p1 = 0; p1 < P; ++p1)
+#pragma unroll
+      for (int p2 = p1; p2 < P; ++p2)
+        S.v[idx] = __builtin_fmaf(H[p1], H[p2], S.v[idx]), ++idx;
+#pragma unroll
+    for (int p1 = 0; p1 < P; ++p1)
+      S.v[SumsT::NA + p1] = __builtin_fmaf(H[p1], V, S.v[SumsT::NA + p1]);
+    S.v[SumsT::N - 1] = __builtin_fmaf(V, V, S.v[SumsT::N - 1]);
+  }
+  // reconverged: all 64 lanes of every wave are active from here on
+#pragma unroll
+  for (int i = 0; i < SumsT::N; ++i)
+    S.v[i] = wave_sum(S.v[i]);
+  bool any_bad = __ballot(bad) != 0ull;
+  if constexpr (WAVES > 1) {
+    const int wave = (int)threadIdx.x / kWave, lane = (int)threadIdx.x % kWave;
+    constexpr int STRIDE = SumsT::N + 1;
+    __syncthreads(); // previous readers of lds are done
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < SumsT::N; ++i)
+        lds[wave * STRIDE + i] = S.v[i];
+      lds[wave * STRIDE + SumsT::N] = any_bad ? 1.f : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SumsT::N; ++i) {
+      float t = lds[i];
+      for (int w = 1; w < WAVES; ++w)
+        t += lds[w * STRIDE + i];
+      S.v[i] = t;
+    }
+    float eb = 0.f;
+    for (int w = 0; w < WAVES; ++w)
+      eb += lds[w * STRIDE + SumsT::N];
+    any_bad = eb != 0.f;
+  }
+  return any_bad;
+}
+
+// ------------------------------------------------------------------------------------
+// 6x6 solve: Eigen 3.4.0 ColPivHouseholderQR restated (the reference's only solver call,
+// correlation_class.cpp:742-747).  Same statement order as oracle/lk_oracle.c's
+// lko_colpiv_qr_solve so that both give the same bits for the same input.  All indices are
+// compile-time after unrolling; the (wave-uniform) pivot choice is applied with
+// compare-and-swap so nothing is dynamically indexed (no scratch).
+// M is column-major N x N, overwritten.
+// ------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void colpiv_qr_solve(float (&M)[N * N], const float (&bin)[N],
+                                                float (&x)[N]) {
+#define QR(r, c) M[(c)*N + (r)]
+  float hc[N], normU[N], normD[N], cv[N];
+  int trans[N];
+  const float eps = FLT_EPSILON;
+  float maxn = 0.f;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+      s += QR(r, k) * QR(r, k);
+    normD[k] = __builtin_sqrtf(s);
+    normU[k] = normD[k];
+    if (normU[k] > maxn)
+      maxn = normU[k];
+  }
+  const float threshold_helper = (maxn * eps) * (maxn * eps) / (float)N;
+  const float norm_downdate_threshold = __builtin_sqrtf(eps);
+  int nonzero_pivots = N;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    int big = k;
+    float bigv = normU[k];
+#pragma unroll
+    for (int j = k + 1; j < N; ++j)
+      if (normU[j] > bigv) {
+        bigv = normU[j];
+        big = j;
+      }
+    float big_sq = bigv * bigv;
+    if (nonzero_pivots == N && big_sq < threshold_helper * (float)(N - k))
+      nonzero_pivots = k;
+    trans[k] = big;
+#pragma unroll
+    for (int j = k + 1; j < N; ++j) {
+      if (big == j) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+          float t = QR(r, k);
+          QR(r, k) = QR(r, j);
+          QR(r, j) = t;
+        }
+        float t = normU[k];
+        normU[k] = normU[j];
+        normU[j] = t;
+        t = normD[k];
+        normD[k] = normD[j];
+        normD[j] = t;
+      }
+    }
+    float tailSq = 0.f;
+#pragma unroll
+    for (int r = k + 1; r < N; ++r)
+      tailSq += QR(r, k) * QR(r, k);
+    float c0 = QR(k, k), beta, tau;
+    if (tailSq <= FLT_MIN) {
+      tau = 0.f;
+      beta = c0;
+#pragma unroll
+      for (int r = k + 1; r < N; ++r)
+        QR(r, k) = 0.f;
+    } else {
+      beta = __builtin_sqrtf(c0 * c0 + tailSq);
+      if (c0 >= 0.f)
+        beta = -beta;
+      float den = c0 - beta;
+#pragma unroll
+      for (int r = k + 1; r < N; ++r)
+        QR(r, k) = QR(r, k) / den;
+      tau = (beta - c0) / beta;
+    }
+    hc[k] = tau;
+    QR(k, k) = beta;
+    if (N - k > 1 && tau != 0.f) {
+#pragma unroll
+      for (int j = k + 1; j < N; ++j) {
+        float tmp = 0.f;
+#pragma unroll
+        for (int r = k + 1; r < N; ++r)
+          tmp += QR(r, k) * QR(r, j);
+        tmp += QR(k, j);
+        QR(k, j) -= tau * tmp;
+#pragma unroll
+        for (int r = k + 1; r < N; ++r)
+          QR(r, j) -= tmp * (tau * QR(r, k));
+      }
+    }
+#pragma unroll
+    for (int j = k + 1; j < N; ++j) {
+      if (normU[j] != 0.f) {
+        float temp = __builtin_fabsf(QR(k, j)) / normU[j];
+        temp = (1.f + temp) * (1.f - temp);
+        temp = temp < 0.f ? 0.f : temp;
+        float ratio = normU[j] / normD[j];
+        float temp2 = temp * (ratio * ratio);
+        if (temp2 <= norm_downdate_threshold) {
+          float s = 0.f;
+#pragma unroll
+          for (int r = k + 1; r < N; ++r)
+            s += QR(r, j) * QR(r, j);
+          normD[j] = __builtin_sqrtf(s);
+          normU[j] = normD[j];
+        } else {
+          normU[j] *= __builtin_sqrtf(temp);
+        }
+      }
+    }
+  }
+  if (nonzero_pivots == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      x[i] = 0.f;
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    cv[i] = bin[i];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (k < nonzero_pivots) {
+      if (N - k == 1) {
+        cv[k] *= 1.f - hc[k];
+      } else if (hc[k] != 0.f) {
+        float tmp = 0.f;
+#pragma unroll
+        for (int r = k + 1; r < N; ++r)
+          tmp += QR(r, k) * cv[r];
+        tmp += cv[k];
+        cv[k] -= hc[k] * tmp;
+#pragma unroll
+        for (int r = k + 1; r < N; ++r)
+          cv[r] -= tmp * (hc[k] * QR(r, k));
+      }
+    }
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    if (i < nonzero_pivots) {
+      cv[i] = cv[i] / QR(i, i);
+#pragma unroll
+      for (int r = 0; r < i; ++r)
+        cv[r] -= cv[i] * QR(r, i);
+    } else {
+      cv[i] = 0.f; // rank-deficient tail: dst rows of the dropped pivots are zero
+    }
+  }
+  // x[perm[i]] = cv[i], perm = product of the transpositions (k, trans[k]), applied on the
+  // right in ascending k.  Equivalent, without a dynamically indexed perm[]: start from
+  // y = cv and undo the column swaps in descending k.
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    x[i] = cv[i];
+#pragma unroll
+  for (int k = N - 1; k >= 0; --k) {
+#pragma unroll
+    for (int j = k + 1; j < N; ++j)
+      if (trans[k] == j) {
+        float t = x[k];
+        x[k] = x[j];
+        x[j] = t;
+      }
+  }
+#undef QR
+}
+
+// compute_model_parameters (correlation_class.cpp:642-704): scale b and upper A by 1/n,
+// mirror, damp the diagonal, solve, p += dp.
+template <int P>
+__device__ __forceinline__ void damped_step(const Sums<P> &S, float lambda, float scaling,
+                                            float (&p)[6], float *dp_out = nullptr) {
+  float M[P * P], b[P], dp[P];
+  int idx = 0;
+#pragma unroll
+  for (int p1 = 0; p1 < P; ++p1) {
+    b[p1] = S.v[Sums<P>::NA + p1] * scaling;
+#pragma unroll
+    for (int p2 = p1; p2 < P; ++p2) {
+      float a = S.v[idx++] * scaling;
+      if (p1 == p2)
+        a *= (1.f + lambda);
+      M[p1 * P + p2] = a;
+      M[p2 * P + p1] = a;
+    }
+  }
+  colpiv_qr_solve<P>(M, b, dp);
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    p[i] += dp[i];
+    if (dp_out)
+      dp_out[i] = dp[i];
+  }
+}
+
+// translate_model_parameters (pyramid_class.cpp:260-287)
+template <int P> __device__ __forceinline__ void translate(float (&p)[6], int src, int dst) {
+  float mag = (dst - src > 0) ? 1.f / (float)(1 << (dst - src)) : (float)(1 << (src - dst));
+  p[0] *= mag;
+  if (P > 1)
+    p[1] *= mag;
+}
+
+// ------------------------------------------------------------------------------------
+// the solve kernel: CorrelationClass::Newton_Raphson (correlation_class.cpp:349-640)
+// ------------------------------------------------------------------------------------
+template <int MODEL, int INTERP, int WAVES>
+__global__ void __launch_bounds__(WAVES *kWave) lk_solve_kernel(LkSolveArgs a) {
+  constexpr int P = n_params(MODEL);
+  using SumsT = Sums<P>;
+  __shared__ float lds[WAVES > 1 ? WAVES * (SumsT::N + 1) : 1];
+
+  // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs, so give each
+  // XCD one contiguous run of sectors (neighbouring sectors share image rows in its L2).
+  const int b = (int)blockIdx.x;
+  int slot = (b & 7) * a.chunk + (b >> 3);
+  if (slot >= a.n_sectors)
+    return;
+  const int s = a.order ? (int)a.order[slot] : slot;
+
+  float p[6], lg_p[6], tent[6], saved[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    p[i] = i < P ? a.guess[(size_t)s * 6 + i] : 0.f;
+    lg_p[i] = tent[i] = saved[i] = 0.f;
+  }
+  const float2 c0 = a.center[s];
+  const float min_lambda = 1e-9f, max_lambda = 1e9f;
+  float last_good_chi = FLT_MAX;
+  int reached_iterations = 0;
+  int error_code = LK_ERROR_NONE;
+  uint32_t n_evals = 0, n_sample_evals = 0, n_point_iters = 0;
+  int level_old = 0;
+  bool early = false;
+  SumsT S;
+
+  for (int level = a.py_stop; level >= a.py_start; level -= a.py_step) {
+    const LkLevelView lv = a.lv[level];
+    translate<P>(p, level_old, level);
+    error_code = LK_ERROR_NONE;
+    float lambda = 0.0001f;
+    last_good_chi = FLT_MAX;
+    const uint32_t off = lv.off[s];
+    const int n = (int)(lv.off[s + 1] - off);
+    const float scaling = 1.f / ((float)n);
+    const float inv = 1.f / (float)(1 << level); // pyramid_class.cpp:357-361
+    const float cx = level == 0 ? c0.x : c0.x * inv, cy = level == 0 ? c0.y : c0.y * inv;
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+      lg_p[i] = p[i];
+
+    // evaluation #0 (:410-437)
+    bool err = evaluate<MODEL, INTERP, WAVES>(lv, off, n, cx, cy, p, S, lds);
+    ++n_evals;
+    n_sample_evals += (uint32_t)n;
+    ++n_point_iters;
+    if (err) {
+      error_code = LK_ERROR_INTERPOLATION_OUT_OF_IMAGE;
+      translate<P>(p, level, 0);
+      early = true;
+      break;
+    }
+    float chi = S.v[SumsT::N - 1] * scaling;
+    last_good_chi = chi;
+    damped_step<P>(S, lambda, scaling, p);
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+      saved[i] = p[i];
+    bool use_saved = true;
+
+    for (int iteration = 1; iteration <= a.max_iters + 1; ++iteration) {
+      if (iteration > a.max_iters || lambda >= max_lambda) {
+        error_code = LK_ERROR_CORRELATION_MAX_ITERS_REACHED;
+        break;
+      }
+      reached_iterations = iteration;
+      ++n_point_iters;
+      if (use_saved) {
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+          tent[i] = saved[i];
+      } else { // reject path: re-evaluate at last_good with the larger lambda (:475-499)
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+          p[i] = lg_p[i];
+        err = evaluate<MODEL, INTERP, WAVES>(lv, off, n, cx, cy, p, S, lds);
+        ++n_evals;
+        n_sample_evals += (uint32_t)n;
+        if (err) {
+          error_code = LK_ERROR_INTERPOLATION_OUT_OF_IMAGE;
+          break;
+        }
+        damped_step<P>(S, lambda, scaling, p);
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+          tent[i] = p[i];
+      }
+#pragma unroll
+      for (int i = 0; i < P; ++i)
+        p[i] = tent[i];
+      err = evaluate<MODEL, INTERP, WAVES>(lv, off, n, cx, cy, p, S, lds);
+      ++n_evals;
+      n_sample_evals += (uint32_t)n;
+      chi = S.v[SumsT::N - 1] * scaling;
+      if (err) {
+        error_code = LK_ERROR_INTERPOLATION_OUT_OF_IMAGE;
+        break;
+      }
+      // look-ahead step with the next lambda (:523-529)
+      damped_step<P>(S, fmaxf(lambda * 0.4f, min_lambda), scaling, p);
+#pragma unroll
+      for (int i = 0; i < P; ++i)
+        saved[i] = p[i];
+      float delta_chi =
+          __builtin_fabsf((last_good_chi - chi) / (fmaxf(last_good_chi, chi) + a.precision));
+      if (chi <= last_good_chi) {
+        last_good_chi = chi;
+        lambda = fmaxf(lambda * 0.4f, min_lambda);
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+          lg_p[i] = tent[i];
+        use_saved = true;
+      } else {
+        lambda = fminf(lambda * 10.0f, max_lambda);
+        use_saved = false;
+      }
+      if (delta_chi < a.precision)
+        break;
+    }
+    level_old = level;
+  }
+  if (!early)
+    translate<P>(p, level_old, 0);
+
+  if (threadIdx.x == 0) {
+    lk_result r;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      r.resultingParameters[i] = i < P ? p[i] : 0.f;
+    r.chi = last_good_chi;
+    r.numberOfPoints = (int)(a.lv[0].off[s + 1] - a.lv[0].off[s]);
+    r.iterations = reached_iterations;
+    r.errorCode = error_code;
+    r.undCenterX = c0.x;
+    r.undCenterY = c0.y;
+    a.result[s] = r;
+    if (a.last_p) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        a.last_p[(size_t)s * 6 + i] = r.resultingParameters[i];
+    }
+    if (a.stats) {
+      a.stats[(size_t)s * 4 + 0] = n_evals;
+      a.stats[(size_t)s * 4 + 1] = n_sample_evals;
+      a.stats[(size_t)s * 4 + 2] = n_point_iters;
+      a.stats[(size_t)s * 4 + 3] = 0;
+    }
+  }
+}
+
+// stand-alone evaluation of one sector/level (known-answer tests): same evaluate<>()
+template <int MODEL, int INTERP, int WAVES>
+__global__ void __launch_bounds__(WAVES *kWave) lk_eval_kernel(LkEvalArgs a) {
+  constexpr int P = n_params(MODEL);
+  using SumsT = Sums<P>;
+  __shared__ float lds[WAVES > 1 ? WAVES * (SumsT::N + 1) : 1];
+  const LkLevelView lv = a.lv[a.level];
+  const uint32_t off = lv.off[a.sector];
+  const int n = (int)(lv.off[a.sector + 1] - off);
+  const float2 c0 = a.center[a.sector];
+  const float inv = 1.f / (float)(1 << a.level);
+  const float cx = a.level == 0 ? c0.x : c0.x * inv, cy = a.level == 0 ? c0.y : c0.y * inv;
+  float p[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+    p[i] = a.p[i];
+  SumsT S;
+  bool err = evaluate<MODEL, INTERP, WAVES>(lv, off, n, cx, cy, p, S, lds);
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 44; ++i)
+      a.out[i] = 0.f;
+    int idx = 0;
+    for (int p1 = 0; p1 < P; ++p1)
+      for (int p2 = p1; p2 < P; ++p2)
+        a.out[p1 * 6 + p2] = S.v[idx++];
+    for (int p1 = 0; p1 < P; ++p1)
+      a.out[36 + p1] = S.v[SumsT::NA + p1];
+    a.out[42] = S.v[SumsT::N - 1];
+    a.out[43] = err ? 1.f : 0.f;
+  }
+}
+
+// stand-alone sampling of the deformed image at arbitrary points (known-answer tests):
+// out[k] = {W, dW/dx, dW/dy, error}
+template <int INTERP>
+__global__ void lk_sample_kernel(const uint8_t *def, int rows, int cols, const float2 *pts, int n,
+                                 float4 *out) {
+  int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (k >= n)
+    return;
+  float W = 0.f, Wx = 0.f, Wy = 0.f;
+  bool ok = sample_def<INTERP>(def, rows, cols, pts[k].x, pts[k].y, W, Wx, Wy);
+  out[k] = ok ? make_float4(W, Wx, Wy, 0.f) : make_float4(0.f, 0.f, 0.f, 1.f);
+}
+
+// stand-alone damped solve: in = [A row-major 6x6 upper (36), b (6), lambda, scaling]
+template <int P> __global__ void lk_solve_only_kernel(const float *in, float *dp_out) {
+  Sums<P> S;
+  int idx = 0;
+  for (int p1 = 0; p1 < P; ++p1)
+    for (int p2 = p1; p2 < P; ++p2)
+      S.v[idx++] = in[p1 * 6 + p2];
+  for (int p1 = 0; p1 < P; ++p1)
+    S.v[Sums<P>::NA + p1] = in[36 + p1];
+  S.v[Sums<P>::N - 1] = 0.f;
+  float p[6] = {0, 0, 0, 0, 0, 0}, dp[6] = {0, 0, 0, 0, 0, 0};
+  damped_step<P>(S, in[42], in[43], p, dp);
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    for (int i = 0; i < 6; ++i)
+      dp_out[i] = i < P ? dp[i] : 0.f;
+}
+
+// ------------------------------------------------------------------------------------
+// pyramid: 5x5 Gaussian, /2 decimation, CPU-engine arithmetic (pyramid_class.cpp:83-122):
+// weights are float products km[i]*km[j], the 25 terms are accumulated in (dj outer, di
+// inner) order with separate multiply and add, the result is truncated to u8, and the
+// one-pixel border of the target stays 0.
+// Each thread produces 4 horizontally adjacent target pixels (one dword store) from a
+// 5-row x 11-byte source window.
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) lk_pyramid_kernel(const uint8_t *__restrict__ src,
+                                                         int srows, int scols,
+                                                         uint8_t *__restrict__ dst) {
+  const int tcols = scols / 2, trows = srows / 2;
+  const int tj = (int)(blockIdx.y * blockDim.y + threadIdx.y);
+  const int ti0 = (int)(blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (tj >= trows || ti0 >= tcols)
+    return;
+  const float km[5] = {0.05f, 0.25f, 0.4f, 0.25f, 0.05f};
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool row_inside = tj >= 1 && tj < trows - 1;
+  if (row_inside) {
+#pragma unroll
+    for (int dj = -2; dj <= 2; ++dj) {
+      const uint8_t *row = src + (size_t)(2 * tj + dj) * (size_t)scols;
+      // source columns 2*ti0-2 .. 2*ti0+8 (11 bytes), clamped loads for the border threads
+      float px[11];
+#pragma unroll
+      for (int c = 0; c < 11; ++c) {
+        int sc = 2 * ti0 - 2 + c;
+        sc = min(max(sc, 0), scols - 1);
+        px[c] = (float)row[sc];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int di = 0; di < 5; ++di)
+          acc[t] += px[2 * t + di] * (km[di] * km[dj + 2]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    int ti = ti0 + t;
+    if (ti < tcols) {
+      bool inside = row_inside && ti >= 1 && ti < tcols - 1;
+      dst[(size_t)tj * (size_t)tcols + (size_t)ti] = inside ? (uint8_t)acc[t] : (uint8_t)0;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// initial-guess policy for every sector (managerClass::adjust_initial_guess,
+// manager_class.cpp:2602-2707)
+// ------------------------------------------------------------------------------------
+struct LkGuessArgs {
+  const float2 *center;
+  const float *last_p; // results of the previous frame [S][6]
+  float *prev_p;       // previous_resulting_parameters [S][6]
+  float *guess;        // out [S][6]
+  float global_guess[6];
+  float gcx, gcy;
+  int n_sectors, model, frame, constant_velocity;
+};
+
+__global__ void lk_guess_kernel(LkGuessArgs a) {
+  int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (s >= a.n_sectors)
+    return;
+  const int P = n_params(a.model);
+  float g[6] = {0, 0, 0, 0, 0, 0};
+  if (a.frame == 0) {
+    for (int i = 0; i < P; ++i)
+      g[i] = a.global_guess[i];
+    float2 c = a.center[s];
+    float dx = c.x - a.gcx, dy = c.y - a.gcy;
+    if (a.model == LK_FM_UVUXUYVXVY) {
+      g[0] += dx * a.global_guess[2] + dy * a.global_guess[3];
+      g[1] += dx * a.global_guess[4] + dy * a.global_guess[5];
+    } else {
+      float Vx = a.global_guess[2];
+      g[0] += -dy * Vx;
+      g[1] += dx * Vx;
+    }
+    for (int i = 0; i < 6; ++i)
+      a.prev_p[(size_t)s * 6 + i] = i < P ? g[i] : 0.f;
+  } else {
+    for (int i = 0; i < P; ++i) {
+      float r = a.last_p[(size_t)s * 6 + i], q = a.prev_p[(size_t)s * 6 + i];
+      g[i] = a.constant_velocity ? r + (r - q) : r;
+      a.prev_p[(size_t)s * 6 + i] = r;
+    }
+  }
+  for (int i = 0; i < 6; ++i)
+    a.guess[(size_t)s * 6 + i] = i < P ? g[i] : 0.f;
+}
+
+// warp a sample list by p (kModel_inPlace, correlationKernel.cu:56-110; getDefXY0)
+__global__ void lk_warp_points_kernel(const float2 *xy, int n, float cx, float cy, int model,
+                                      const float *pp, float2 *out) {
+  int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (k >= n)
+    return;
+  float p[6];
+  for (int i = 0; i < 6; ++i)
+    p[i] = pp[i];
+  float2 q = xy[k];
+  float xd, yd, dx, dy;
+  switch (model) {
+  case LK_FM_U: Warp<LK_FM_U>::apply(q.x, q.y, cx, cy, p, xd, yd, dx, dy); break;
+  case LK_FM_UV: Warp<LK_FM_UV>::apply(q.x, q.y, cx, cy, p, xd, yd, dx, dy); break;
+  case LK_FM_UVQ: Warp<LK_FM_UVQ>::apply(q.x, q.y, cx, cy, p, xd, yd, dx, dy); break;
+  default: Warp<LK_FM_UVUXUYVXVY>::apply(q.x, q.y, cx, cy, p, xd, yd, dx, dy); break;
+  }
+  out[k] = make_float2(xd, yd);
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------
+// launch wrappers (called from lk_engine.cpp)
+// ------------------------------------------------------------------------------------
+template <int MODEL, int INTERP>
+static hipError_t launch_solve_mi(const LkSolveArgs &a, int waves, hipStream_t st) {
+  dim3 grid((unsigned)(a.chunk * 8));
+  switch (waves) {
+  case 1: hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, 1>), grid, dim3(64), 0, st, a); break;
+  case 4: hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, 4>), grid, dim3(256), 0, st, a); break;
+  default: hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, 8>), grid, dim3(512), 0, st, a); break;
+  }
+  return hipGetLastError();
+}
+
+template <int MODEL>
+static hipError_t launch_solve_m(const LkSolveArgs &a, int interp, int waves, hipStream_t st) {
+  switch (interp) {
+  case LK_IM_NEAREST: return launch_solve_mi<MODEL, LK_IM_NEAREST>(a, waves, st);
+  case LK_IM_BILINEAR: return launch_solve_mi<MODEL, LK_IM_BILINEAR>(a, waves, st);
+  default: return launch_solve_mi<MODEL, LK_IM_BICUBIC>(a, waves, st);
+  }
+}
+
+hipError_t lk_launch_solve(const LkSolveArgs &a, int model, int interp, int waves, hipStream_t st) {
+  if (a.n_sectors <= 0)
+    return hipSuccess;
+  switch (model) {
+  case LK_FM_U: return launch_solve_m<LK_FM_U>(a, interp, waves, st);
+  case LK_FM_UV: return launch_solve_m<LK_FM_UV>(a, interp, waves, st);
+  case LK_FM_UVQ: return launch_solve_m<LK_FM_UVQ>(a, interp, waves, st);
+  default: return launch_solve_m<LK_FM_UVUXUYVXVY>(a, interp, waves, st);
+  }
+}
+
+template <int MODEL>
+static hipError_t launch_eval_m(const LkEvalArgs &a, int interp, hipStream_t st) {
+  switch (interp) {
+  case LK_IM_NEAREST: hipLaunchKernelGGL((lk_eval_kernel<MODEL, LK_IM_NEAREST, 4>), dim3(1), dim3(256), 0, st, a); break;
+  case LK_IM_BILINEAR: hipLaunchKernelGGL((lk_eval_kernel<MODEL, LK_IM_BILINEAR, 4>), dim3(1), dim3(256), 0, st, a); break;
+  default: hipLaunchKernelGGL((lk_eval_kernel<MODEL, LK_IM_BICUBIC, 4>), dim3(1), dim3(256), 0, st, a); break;
+  }
+  return hipGetLastError();
+}
+
+hipError_t lk_launch_eval(const LkEvalArgs &a, int model, int interp, hipStream_t st) {
+  switch (model) {
+  case LK_FM_U: return launch_eval_m<LK_FM_U>(a, interp, st);
+  case LK_FM_UV: return launch_eval_m<LK_FM_UV>(a, interp, st);
+  case LK_FM_UVQ: return launch_eval_m<LK_FM_UVQ>(a, interp, st);
+  default: return launch_eval_m<LK_FM_UVUXUYVXVY>(a, interp, st);
+  }
+}
+
+hipError_t lk_launch_solve_only(int n, const float *d_in, float *d_out, hipStream_t st) {
+  switch (n) {
+  case 1: hipLaunchKernelGGL((lk_solve_only_kernel<1>), dim3(1), dim3(64), 0, st, d_in, d_out); break;
+  case 2: hipLaunchKernelGGL((lk_solve_only_kernel<2>), dim3(1), dim3(64), 0, st, d_in, d_out); break;
+  case 3: hipLaunchKernelGGL((lk_solve_only_kernel<3>), dim3(1), dim3(64), 0, st, d_in, d_out); break;
+  case 6: hipLaunchKernelGGL((lk_solve_only_kernel<6>), dim3(1), dim3(64), 0, st, d_in, d_out); break;
+  default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t lk_launch_sample(int interp, const uint8_t *def, int rows, int cols, const float2 *pts, int n,
+                            float4 *out, hipStream_t st) {
+  if (n <= 0)
+    return hipSuccess;
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  switch (interp) {
+  case LK_IM_NEAREST: hipLaunchKernelGGL((lk_sample_kernel<LK_IM_NEAREST>), grid, block, 0, st, def, rows, cols, pts, n, out); break;
+  case LK_IM_BILINEAR: hipLaunchKernelGGL((lk_sample_kernel<LK_IM_BILINEAR>), grid, block, 0, st, def, rows, cols, pts, n, out); break;
+  default: hipLaunchKernelGGL((lk_sample_kernel<LK_IM_BICUBIC>), grid, block, 0, st, def, rows, cols, pts, n, out); break;
+  }
+  return hipGetLastError();
+}
+
+hipError_t lk_launch_pyramid(const uint8_t *src, int srows, int scols, uint8_t *dst, hipStream_t st) {
+  int tcols = scols / 2, trows = srows / 2;
+  if (tcols <= 0 || trows <= 0)
+    return hipSuccess;
+  dim3 block(64, 4);
+  dim3 grid((unsigned)((tcols + 4 * 64 - 1) / (4 * 64)), (unsigned)((trows + 3) / 4));
+  hipLaunchKernelGGL(lk_pyramid_kernel, grid, block, 0, st, src, srows, scols, dst);
+  return hipGetLastError();
+}
+
+hipError_t lk_launch_guess(const float2 *center, const float *last_p, float *prev_p, float *guess,
+                           const float *global_guess, float gcx, float gcy, int n_sectors, int model,
+                           int frame, int constant_velocity, hipStream_t st) {
+  LkGuessArgs a;
+  a.center = center;
+  a.last_p = last_p;
+  a.prev_p = prev_p;
+  a.guess = guess;
+  for (int i = 0; i < 6; ++i)
+    a.global_guess[i] = global_guess[i];
+  a.gcx = gcx;
+  a.gcy = gcy;
+  a.n_sectors = n_sectors;
+  a.model = model;
+  a.frame = frame;
+  a.constant_velocity = constant_velocity;
+  if (n_sectors <= 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(lk_guess_kernel, dim3((unsigned)((n_sectors + 255) / 256)), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t lk_launch_warp_points(const float2 *xy, int n, float cx, float cy, int model, const float *d_p,
+                                 float2 *out, hipStream_t st) {
+  if (n <= 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(lk_warp_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xy, n, cx,
+                     cy, model, d_p, out);
+  return hipGetLastError();
+}

@@ -1,0 +1,195 @@
+/* lk_engine.h - C-ABI of the MI355X (gfx950) Lucas-Kanade correlation engine.
+ *
+ * Drop-in boundary for the hot path of namascar/correlation: everything the reference's
+ * managerClass asks of its GPU engine `CudaClass` (cuda_class.cuh:46-79) and of its CPU
+ * engine `CorrelationClass` (correlation_class.hpp:132-179) for ONE image pair:
+ * image pyramids, ROI -> sample lists, and the per-sector coarse-to-fine
+ * Levenberg-Marquardt solve.  Plain C types only; no OpenCV / Qt / torch types.
+ *
+ * Conventions
+ *  - every function returns an `lk_error` (the reference's errorEnum values,
+ *    enums.hpp:25-35); the engine never calls exit() (the reference does on CUDA errors,
+ *    cuda_class.cu:52-56).  lk_last_error_string() describes the last failure.
+ *  - the caller owns every buffer it passes in or receives results in; the engine copies
+ *    during the call and never returns pointers into its own memory (the reference
+ *    returns a pointer to engine-owned pinned memory, cuda_polygon.cuh:339-340).
+ *  - results follow the CPU engine's semantics (SURVEY.md section 8a-a13 lists where the
+ *    reference's CUDA path differs): look-ahead parameters are returned, `iterations` is
+ *    the last pyramid level's trip count, chi is the 1/n-scaled last_good_chi.
+ *  - one caller thread at a time, except lk_set_image(LK_IMG_NXT) which may overlap a
+ *    running lk_correlate_* (manager_class.cpp:1438-1447 prefetches the next frame).
+ */
+#ifndef LK_ENGINE_H
+#define LK_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LK_MAX_LEVELS 8
+#define LK_MAX_PARAMS 6
+
+/* errorEnum, enums.hpp:25-35 (same numeric values) */
+typedef enum {
+  LK_ERROR_NONE = 0,
+  LK_ERROR_MODEL_OUT_OF_IMAGE = 1,
+  LK_ERROR_INTERPOLATION_OUT_OF_IMAGE = 2,
+  LK_ERROR_CORRELATION_MAX_ITERS_REACHED = 3,
+  LK_ERROR_BAD_DOMAIN = 4,
+  LK_ERROR_SOLVER = 5, /* error_cuSolver */
+  LK_ERROR_DEVICE = 6, /* error_cuda: any HIP failure */
+  LK_ERROR_MULTITHREAD = 7
+} lk_error;
+
+/* interpolationModelEnum, enums.hpp:10-15 */
+typedef enum { LK_IM_NEAREST = 0, LK_IM_BILINEAR = 1, LK_IM_BICUBIC = 2 } lk_interpolation;
+/* fittingModelEnum, enums.hpp:17-23: p = (u), (u,v), (u,v,q), (u,v,ux,uy,vx,vy) */
+typedef enum { LK_FM_U = 0, LK_FM_UV = 1, LK_FM_UVQ = 2, LK_FM_UVUXUYVXVY = 3 } lk_fitting_model;
+/* ImageType, enums.hpp:94-99 */
+typedef enum { LK_IMG_UND = 0, LK_IMG_DEF = 1, LK_IMG_NXT = 2 } lk_image_slot;
+
+/* CorrelationClass ctor arguments (correlation_class.hpp:132-137) +
+ * CudaClass::set_* (cuda_class.cu:77-102) + resetImagePyramids' start/step/stop (:475) */
+typedef struct {
+  int interpolation;   /* lk_interpolation, default im_bicubic (mainapp.cpp:64) */
+  int fitting_model;   /* lk_fitting_model */
+  float precision;     /* required_precision, default 1e-3 */
+  int max_iters;       /* maximum_iterations, default 50 */
+  int py_start, py_step, py_stop; /* pyramid levels, default 0/1/2 */
+  int device;          /* HIP device ordinal this engine lives on */
+} lk_config;
+
+/* layout-identical to CorrelationResult (domains.hpp:110-118), 48 bytes */
+typedef struct {
+  float resultingParameters[6];
+  float chi;
+  int numberOfPoints;
+  int iterations;
+  int errorCode; /* lk_error */
+  float undCenterX;
+  float undCenterY;
+} lk_result;
+
+/* counters of the last lk_correlate_* call, for the bench */
+typedef struct {
+  uint64_t sectors;
+  uint64_t evaluations;       /* warp+sample+accumulate passes over one sector */
+  uint64_t sample_evaluations;/* sum over evaluations of the sector's n_L */
+  uint64_t point_iterations;  /* per sector and level: LM trips + 1 (evaluation #0) */
+  uint64_t algorithmic_bytes; /* 25*sample_evaluations + 196*evaluations */
+  float solve_ms;             /* HIP-event time of the solve kernel(s) of the last call */
+  float pyramid_ms;           /* HIP-event time of the last pyramid build */
+} lk_stats;
+
+typedef struct lk_engine lk_engine;
+
+/* ---- life cycle ------------------------------------------------------------------- */
+/* CudaClass::initialize (cuda_class.cu:39-75): number of usable devices */
+int lk_device_count(void);
+/* CorrelationClass ctor / CudaClass ctor + set_* */
+int lk_create(const lk_config *cfg, lk_engine **out);
+void lk_destroy(lk_engine *e);
+const char *lk_last_error_string(const lk_engine *e);
+/* run all engine work on a caller-provided hipStream_t (NULL = engine's own stream) */
+int lk_set_stream(lk_engine *e, void *hip_stream);
+/* block until everything queued by this engine has finished */
+int lk_synchronize(lk_engine *e);
+
+/* ---- images and pyramids ---------------------------------------------------------- */
+/* CorrelationClass::set_undeformed/deformed/next_image (correlation_class.cpp:38-51),
+ * CudaClass::resetImagePyramids / resetNextPyramid (cuda_class.cu:475-559): upload the
+ * level-0 pixels (monochrome u8, `step` bytes per row) and build levels 1..py_stop.
+ * File decoding stays with the caller. */
+int lk_set_image(lk_engine *e, int slot, const uint8_t *host_pixels, int rows, int cols, int step);
+/* same, pixels already in this device's memory (used after an RCCL broadcast) */
+int lk_set_image_device(lk_engine *e, int slot, const void *device_pixels, int rows, int cols, int step);
+/* CorrelationClass::set_und_image_from_def / set_def_image_from_nxt
+ * (correlation_class.cpp:53-61), CudaClass::makeUndPyramidFromDef / makeDefPyramidFromNxt
+ * (cuda_class.cu:561-567): pointer rotation, no copies */
+int lk_rotate_und_from_def(lk_engine *e);
+int lk_rotate_def_from_nxt(lk_engine *e);
+/* download one pyramid level (cudaImage::testPyramid, cuda_pyramid.cu:304-346);
+ * host_out may be NULL to query the size */
+int lk_get_pyramid_level(lk_engine *e, int slot, int level, uint8_t *host_out, int *rows, int *cols);
+
+/* ---- sectors (ROI -> sample lists) ------------------------------------------------ */
+/* forget all sectors */
+int lk_clear_sectors(lk_engine *e);
+/* CudaClass::resetPolygon(iSector,x0,y0,x1,y1) (cuda_class.cu:574-582) with the CPU
+ * path's sample order (x outer, y inner, inclusive; manager_class.cpp:1596-1614) and
+ * centre ((x0+x1)/2,(y0+y1)/2) = the integer centre the manager passes (:438-441) */
+int lk_set_sector_rect(lk_engine *e, int sector, int x0, int y0, int x1, int y1);
+/* the whole rectangular prologue (manager_class.cpp:276-310): hs*vs sectors,
+ * iSector = i*vs + j; registers sectors [first, first+count) of that grid as engine
+ * sectors 0..count-1 (count<0: all) - the multi-GPU shard entry point */
+int lk_set_rect_grid(lk_engine *e, float x_begin, float y_begin, float x_end, float y_end,
+                     int hs, int vs, int first, int count);
+/* CudaClass::resetPolygon(iSector,r,dr,a,da,cx,cy,as) (cuda_class.cu:584-594) with the
+ * CPU path's predicate and order (manager_class.cpp:816-940); centre = float mean */
+int lk_set_sector_annular(lk_engine *e, int sector, float r, float dr, float a, float da,
+                          float cx, float cy, int as);
+/* CudaClass::resetPolygon(v_points) (cuda_class.cu:596-605) with polygonBlob_class
+ * semantics (polygon_class.cpp:224-429); LK_ERROR_BAD_DOMAIN on a self-intersecting
+ * contour (manager_class.cpp:1028-1031) */
+int lk_set_sector_blob(lk_engine *e, int sector, const float *contour_xy, int n_vertices);
+/* CorrelationClass::Newton_Raphson(p, n, xy) / (p, n, cx, cy, xy)
+ * (correlation_class.cpp:306-343): explicit AoS sample list; use_center=0 -> float mean */
+int lk_set_sector_points(lk_engine *e, int sector, const float *xy, int n, int use_center,
+                         float cx, float cy);
+/* build per-level sample lists (pyramid_class.cpp:289-362) and upload; must be called
+ * after the lk_set_sector_* calls and before lk_correlate_* */
+int lk_commit_sectors(lk_engine *e);
+int lk_sector_count(const lk_engine *e);
+/* CorrelationClass::get_number_of_points / get_und_x/y_center (correlation_class.cpp:850-868) */
+int lk_get_sector_info(lk_engine *e, int sector, int *n_points, float *cx, float *cy);
+/* number of samples of a sector at a pyramid level (pyramid_class.cpp:437-439) */
+int lk_get_sector_level_count(lk_engine *e, int sector, int level, int *n);
+/* CudaClass::getUndXY0ToCPU / CorrelationClass::getUndXY0 (cuda_class.cu:607-609):
+ * returns the count; copies min(count, cap) AoS pairs */
+int lk_get_und_xy(lk_engine *e, int sector, float *xy, int cap, int *count);
+/* CudaClass::getDefXY0ToCPU / CorrelationClass::getDefXY0 (cuda_class.cu:611-613,
+ * kModel_inPlace correlationKernel.cu:56-110): level-0 samples warped by p */
+int lk_get_def_xy(lk_engine *e, int sector, const float *p, float *xy, int cap, int *count);
+
+/* ---- the solve -------------------------------------------------------------------- */
+/* CudaClass::correlate(iSector, guess, results) (cuda_class.cu:104-293) /
+ * CorrelationClass::Newton_Raphson: one sector; guess is in/out like the reference
+ * (cuda_class.cu:289-290, correlation_class.cpp:360) */
+int lk_correlate(lk_engine *e, int sector, float *guess_inout, lk_result *out);
+/* all sectors in one device-resident batch (one launch per size class).
+ * guesses: [S][6] host floats (unused slots ignored); out: [S] host records */
+int lk_correlate_all(lk_engine *e, const float *guesses, lk_result *out);
+/* same with device buffers, asynchronous on the engine's stream; d_guesses may be NULL
+ * to use the engine-held guesses written by lk_adjust_initial_guess */
+int lk_correlate_all_device(lk_engine *e, const void *d_guesses, void *d_results);
+
+/* managerClass::adjust_initial_guess (manager_class.cpp:2602-2707), batched on the
+ * device for every sector: frame 0 -> global guess + strain*(sector centre - global
+ * centre); later frames -> constant_velocity ? 2*p_prev - p_prevprev : p_prev, where
+ * p_prev are the results of the previous lk_correlate_all*. */
+int lk_adjust_initial_guess(lk_engine *e, int frame, int constant_velocity,
+                            const float *global_guess, float global_cx, float global_cy);
+/* copy the engine-held guesses ([S][6]) to the host */
+int lk_get_guesses(lk_engine *e, float *guesses);
+
+/* ---- stand-alone pieces (known-answer tests, same kernels as the batch path) ------- */
+/* one evaluation of one sector at one level: raw sums A (6x6 row-major, upper valid),
+ * b, chi (unscaled), error flag (apply_model_and_interpolate, correlation_class.cpp:131) */
+int lk_evaluate(lk_engine *e, int sector, int level, const float *p, float *A36, float *b6,
+                float *chi, int *error);
+/* value and gradient of image `slot` at pyramid `level` at n arbitrary points
+ * (InterpolationClass::get_interpolation, interpolation_class.cpp:79-226), with the
+ * engine's interpolation model: out4[k] = {W, dW/dx, dW/dy, out_of_image ? 1 : 0} */
+int lk_sample(lk_engine *e, int slot, int level, const float *xy, int n, float *out4);
+/* compute_model_parameters + solve (correlation_class.cpp:642-768) on the device */
+int lk_damped_solve(lk_engine *e, int n, const float *A_rowmajor_upper, const float *b,
+                    float lambda, float scaling, float *dp);
+
+int lk_get_stats(lk_engine *e, lk_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LK_ENGINE_H */
