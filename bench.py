@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path (BASELINE.json metric): correlation-point-iterations/s and
+achieved algorithmic HBM GB/s on the 2048^2 speckle pair of config C2.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one image pair whose level-0 pixels are already
+resident in HBM: build both image pyramids (und, def), solve every sector of the ROI grid
+coarse-to-fine on the device, leave the 48-byte result records in HBM.
+N > 1 ("weak" scaling): one process per GPU; every step rank 0's deformed frame is
+broadcast over RCCL/xGMI, each rank correlates its own 10 000-sector grid (the C2 grid
+shifted by `rank` pixels - a denser measurement grid on the same pair) and the result
+records are all-gathered.  value = point-iterations of ALL ranks / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+
+
+def cpu_baseline(wl, und, dfm, budget_sectors):
+    """The CPU oracle (a port of the reference's CPU engine, oracle/lk_oracle.c) timed on
+    this box's host cores on a bounded sample of the same workload."""
+    from oracle import lk_oracle as lo  # checker/baseline only - never the measured GPU path
+    o = lo.Oracle(interp=lo.IM_BICUBIC, model=wl.model, py_stop=wl.py_stop)
+    o.set_image(0, und)
+    o.set_image(1, dfm)
+    xdim, ydim, cen = lo.rect_sector_geometry(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, wl.hs, wl.vs)
+    S = len(cen)
+    pick = np.linspace(0, S - 1, min(budget_sectors, S)).astype(np.int64)
+    n = (2 * xdim + 1) * (2 * ydim + 1)
+    cat = np.concatenate([lo.rect_points(cx - xdim, cy - ydim, cx + xdim, cy + ydim) for cx, cy in cen[pick]])
+    off = np.arange(len(pick), dtype=np.int64) * n
+    cnt = np.full(len(pick), n, np.int32)
+    centers = cen[pick].astype(np.float32)
+    cores = os.cpu_count() or 1
+    out = {}
+    for label, threads in (("1_thread", 1), ("all_cores", cores)):
+        t0 = time.perf_counter()
+        res = o.correlate_packed(cat, off, cnt, centers=centers, nthreads=threads)
+        dt = time.perf_counter() - t0
+        out[label] = (len(pick) / dt, dt, threads, res)
+    return out, len(pick)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sectors", type=int, default=10000)
+    args = ap.parse_args()
+
+    import torch
+    import correlation_amd as ca
+    from correlation_amd.workload import C2
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP engine is the product, there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL
+
+    wl = C2
+    und, dfm = ca.speckle.speckle_pair(wl.size, wl.size, p=wl.truth, seed=7)
+    dev = torch.device("cuda", local_rank)
+    d_und = torch.from_numpy(und).to(dev)
+    d_def = torch.from_numpy(dfm).to(dev) if rank == 0 else torch.empty_like(d_und)
+
+    e = ca.HipCorrelationEngine(interpolation=ca.IM_BICUBIC, fitting_model=wl.model, py_stop=wl.py_stop,
+                                device=local_rank)
+    # a dedicated (non-null) HIP stream shared by torch, RCCL and the engine: torch events
+    # recorded on it bracket exactly the engine's launches
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    e.set_stream(stream.cuda_stream)
+    # weak scaling: rank r correlates the C2 grid shifted by r px (same sector size, distinct ROIs)
+    e.set_rect_grid(wl.x_begin + rank, wl.x_begin + rank, wl.x_end + rank - 8 * (world > 1),
+                    wl.x_end + rank - 8 * (world > 1), wl.hs, wl.vs)
+    e.commit_sectors()
+    S = e.n_sectors
+    n0 = e.sector_info(0)[0]
+    d_guess = torch.zeros((S, 6), dtype=torch.float32, device=dev)
+    d_res = torch.empty((S, 48), dtype=torch.uint8, device=dev)
+    d_all = torch.empty((world * S, 48), dtype=torch.uint8, device=dev) if world > 1 else None
+
+    def step():
+        if world > 1:
+            dist.broadcast(d_def, src=0)                       # new frame over RCCL / xGMI
+        e.set_image_device(ca.IMG_UND, d_und.data_ptr(), wl.size, wl.size)   # pyramid build (und)
+        e.set_image_device(ca.IMG_DEF, d_def.data_ptr(), wl.size, wl.size)   # pyramid build (def)
+        e.correlate_all_device(d_guess.data_ptr(), d_res.data_ptr())         # the solve
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_res)          # gather of warp parameters
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    st = e.stats()   # counters + the engine's own HIP-event time of the LAST solve launch
+    # per-launch duration of the dominant kernel, measured live with HIP events on the
+    # stream it runs on: K back-to-back solve launches bracketed by two events
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(args.steps):
+        e.correlate_all_device(d_guess.data_ptr(), d_res.data_ptr())
+    e1.record(stream)
+    torch.cuda.synchronize(dev)
+    solve_avg_ms = e0.elapsed_time(e1) / args.steps
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    pit = torch.tensor([float(st["point_iterations"])], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(pit, op=dist.ReduceOp.SUM)
+    dt_max = float(tmax.item())
+    total_pit = float(pit.item()) * args.steps
+
+    res = d_res.cpu().numpy().view(ca.RESULT_DTYPE).reshape(-1)
+    if rank == 0:
+        value = total_pit / dt_max
+        achieved = st["algorithmic_bytes"] / (solve_avg_ms * 1e-3) / 1e9
+        line = {
+            "metric": "correlation-point-iterations/sec",
+            "value": value,
+            "unit": "point-iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt_max / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": wl.name, "sectors_per_gpu": S, "samples_per_sector": n0,
+                       "interpolation": "bicubic", "parallelism": f"sectors sharded x{world}",
+                       "step": "pyramid(und)+pyramid(def)+solve, inputs resident in HBM"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "lk_solve_kernel<affine,bicubic,1 wave/sector>",
+                         "kernel_ms": solve_avg_ms,
+                         "algorithmic_bytes_per_launch": st["algorithmic_bytes"]},
+            "per_pair": {"sectors_per_s": S * world * args.steps / dt_max,
+                         "evaluations": st["evaluations"], "sample_evaluations": st["sample_evaluations"],
+                         "point_iterations": st["point_iterations"],
+                         "mean_point_iterations_per_sector": st["point_iterations"] / S,
+                         "error_free_fraction": float((res["error_code"] == 0).mean()),
+                         "last_solve_ms": st["solve_ms"], "last_pyramid_ms": st["pyramid_ms"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, nsec = cpu_baseline(wl, und, dfm, args.cpu_sectors)
+            pit_per_sector = st["point_iterations"] / S
+            rate_mt, dt_mt, thr_mt, res_mt = base["all_cores"]
+            rate_1, dt_1, _, res_1 = base["1_thread"]
+            line["cpu_baseline"] = {
+                "value": rate_mt * pit_per_sector, "unit": "point-iterations/s", "cores": thr_mt, "kind": "port",
+                "sample": f"{nsec} evenly spaced sectors of the same C2 pair, oracle/lk_oracle.c, OpenMP across "
+                          f"sectors, {dt_mt:.2f} s; point-iterations counted with the GPU run's mean per sector",
+                "single_thread_value": rate_1 * pit_per_sector, "single_thread_seconds": dt_1,
+                "sectors_per_s": rate_mt, "single_thread_sectors_per_s": rate_1,
+            }
+            # the baseline doubles as a full-size parity sample
+            xs = np.linspace(0, S - 1, min(args.cpu_sectors, S)).astype(np.int64)
+            line["parity_vs_cpu"] = {
+                "sectors": int(len(xs)),
+                "max_abs_dp01": float(np.abs(res["p"][xs][:, :2] - res_1["p"][:, :2]).max()),
+                "max_rel_dchi": float((np.abs(res["chi"][xs] - res_1["chi"]) / np.abs(res_1["chi"])).max()),
+                "iterations_equal_fraction": float((res["iterations"][xs] == res_1["iterations"]).mean()),
+            }
+        print(json.dumps(line))
+    e.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

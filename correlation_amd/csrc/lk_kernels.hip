@@ -310,8 +310,8 @@ __device__ __forceinline__ bool evaluate(const LkLevelView &lv, uint32_t off, in
 
 // ------------------------------------------------------------------------------------
 // 6x6 solve: Eigen 3.4.0 ColPivHouseholderQR restated (the reference's only solver call,
-// correlation_class.cpp:742-747).  Same statement order as oracle/lk_oracle.c's
-// lko_colpiv_qr_solve so that both give the same bits for the same input.  All indices are
+// correlation_class.cpp:742-747): column norms with LAPACK-style down-dating, largest
+// remaining column as pivot, Householder reflectors, back-substitution.  All indices are
 // compile-time after unrolling; the (wave-uniform) pivot choice is applied with
 // compare-and-swap so nothing is dynamically indexed (no scratch).
 // M is column-major N x N, overwritten.

@@ -380,16 +380,15 @@ void lko_model_point(int model, float x, float y, float cx, float cy, const floa
 
 /* model_class.cpp compute_model + interpolation_class.cpp:671-764, one thread
  * (correlation_class.cpp:131-300 with number_of_threads = 1). A: row-major P x P, upper. */
-static int evaluate(interp_ctx *ic, int model, int P, const uint8_t *und, int ustep,
-                    const float *xy, int n, float cx, float cy, const float *p, float *A,
-                    float *b, float *chi_out) {
+static int evaluate_chunk(interp_ctx *ic, int model, int P, const uint8_t *und, int ustep,
+                          const float *xy, int n, float cx, float cy, const float *p, float *A,
+                          float *b, float *chi_out) {
   float chi = 0.f;
   for (int i = 0; i < P; ++i) {
     b[i] = 0.f;
     for (int j = 0; j < P; ++j)
       A[i * P + j] = 0.f;
   }
-  ic->error = 0;
   float H[6], dTx[6], dTy[6];
   for (int i = 0; i < n; ++i) {
     float x = xy[2 * i], y = xy[2 * i + 1];
@@ -413,6 +412,40 @@ static int evaluate(interp_ctx *ic, int model, int P, const uint8_t *und, int us
   return ic->error;
 }
 
+/* apply_model_and_interpolate (correlation_class.cpp:131-300): T contiguous chunks
+ * (n/T samples, the first n%T get one more, :169-186), each summed by its own
+ * interpolator from zero, totals accumulated in thread order into flushed A, b, chi
+ * (:253-275); the error flag is the OR over chunks (:277-279). */
+static _Thread_local int g_eval_threads = 1; /* set per engine call; the oracle is single-caller */
+static int evaluate(interp_ctx *ic, int model, int P, const uint8_t *und, int ustep,
+                    const float *xy, int n, float cx, float cy, const float *p, float *A,
+                    float *b, float *chi_out) {
+  int T = g_eval_threads < 1 ? 1 : g_eval_threads;
+  float chi = 0.f;
+  for (int i = 0; i < P; ++i) {
+    b[i] = 0.f;
+    for (int j = 0; j < P; ++j)
+      A[i * P + j] = 0.f;
+  }
+  int err = 0, first = 0;
+  for (int t = 0; t < T; ++t) {
+    int cnt = n / T + (t < n % T ? 1 : 0);
+    float At[36], bt[6], chit;
+    ic->error = 0; /* every interpolator object starts an evaluation clean (:652-653) */
+    err |= evaluate_chunk(ic, model, P, und, ustep, xy + 2 * (size_t)first, cnt, cx, cy, p, At, bt, &chit);
+    chi += chit;
+    for (int p1 = 0; p1 < P; ++p1) {
+      b[p1] += bt[p1];
+      for (int p2 = p1; p2 < P; ++p2)
+        A[p1 * P + p2] += At[p1 * P + p2];
+    }
+    first += cnt;
+  }
+  ic->error = err;
+  *chi_out = chi;
+  return err;
+}
+
 int lko_evaluate(int interp, int model, const uint8_t *und, int urows, int ucols,
                  const uint8_t *def, int drows, int dcols, const float *xy, int n,
                  float cx, float cy, const float *p, float A[36], float b[6], float *chi) {
@@ -420,6 +453,7 @@ int lko_evaluate(int interp, int model, const uint8_t *und, int urows, int ucols
   interp_ctx ic = {interp, def, drows, dcols, NULL, 0};
   int P = lko_n_params(model);
   float At[36], bt[6];
+  g_eval_threads = 1;
   int err = evaluate(&ic, model, P, und, ucols, xy, n, cx, cy, p, At, bt, chi);
   memset(A, 0, 36 * sizeof(float));
   memset(b, 0, 6 * sizeof(float));
@@ -668,6 +702,7 @@ int lko_newton_raphson(lko_engine *e, float *p, int n0, const float *xy, int use
   const int P = e->n_params;
   const lko_image *und = &e->img[LKO_IMG_UND], *def = &e->img[LKO_IMG_DEF];
   int tcount = 0;
+  g_eval_threads = cfg->n_threads;
   if (n_trace)
     *n_trace = 0;
   if (und->n_levels == 0 || def->n_levels == 0 || n0 < 0)

@@ -49,6 +49,11 @@ typedef struct {
   float precision;  /* required_precision */
   int max_iters;    /* maximum_iterations */
   int py_start, py_step, py_stop;
+  int n_threads;    /* number_of_threads of the reference (correlation_class.cpp:169-186,
+                       :253-275): samples are split into this many contiguous chunks, each
+                       summed from zero, chunk totals added in thread order.  0/1 = one
+                       chunk.  (The reference really spawns threads; the arithmetic is the
+                       same, only this split matters for the bits.) */
   int cache_mode;   /* 0: coefficients computed per use (values identical to the
                        reference's lazy cache as long as no out-of-image error has
                        occurred on this def image); 1: emulate the lazy per-pixel

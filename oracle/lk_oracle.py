@@ -22,7 +22,7 @@ N_PARAMS = {0: 1, 1: 2, 2: 3, 3: 6}
 class Config(C.Structure):
     _fields_ = [("interp", C.c_int), ("model", C.c_int), ("precision", C.c_float),
                 ("max_iters", C.c_int), ("py_start", C.c_int), ("py_step", C.c_int),
-                ("py_stop", C.c_int), ("cache_mode", C.c_int)]
+                ("py_stop", C.c_int), ("n_threads", C.c_int), ("cache_mode", C.c_int)]
 
 
 RESULT_DTYPE = np.dtype([("p", np.float32, (6,)), ("chi", np.float32), ("n_points", np.int32),
@@ -92,9 +92,10 @@ class Oracle:
     """The reference's CorrelationClass, restated (see lk_oracle.h)."""
 
     def __init__(self, interp=IM_BICUBIC, model=FM_UVUXUYVXVY, precision=1e-3, max_iters=50,
-                 py_start=0, py_step=1, py_stop=2, cache_mode=0):
+                 py_start=0, py_step=1, py_stop=2, cache_mode=0, n_threads=1):
         self.L = lib()
-        self.cfg = Config(interp, model, precision, max_iters, py_start, py_step, py_stop, cache_mode)
+        self.cfg = Config(interp, model, precision, max_iters, py_start, py_step, py_stop, n_threads,
+                          cache_mode)
         self.n_params = N_PARAMS[model]
         self.h = self.L.lko_create(C.byref(self.cfg))
         if not self.h:
@@ -188,18 +189,26 @@ def bicubic_coeffs(img, ix, iy):
     return out
 
 
-def interpolate(interp, img, x, y):
+def _padded(img):
+    """Two zero guard rows below the image, like the oracle's and the engine's own level
+    buffers: the reference's nearest sampler reads one row past the last one."""
     a = np.ascontiguousarray(img, np.uint8)
+    return np.ascontiguousarray(np.vstack([a, np.zeros((2, a.shape[1]), np.uint8)])), a.shape[0]
+
+
+def interpolate(interp, img, x, y, _pad=None):
+    a, rows = _pad if _pad is not None else _padded(img)
     w, wx, wy = C.c_float(), C.c_float(), C.c_float()
-    err = lib().lko_interpolate(interp, a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], x, y,
+    err = lib().lko_interpolate(interp, a.ctypes.data_as(C.c_void_p), rows, a.shape[1], x, y,
                                 C.byref(w), C.byref(wx), C.byref(wy))
     return w.value, wx.value, wy.value, err
 
 
 def interpolate_many(interp, img, xy):
     out = np.zeros((len(xy), 4), np.float32)
+    pad = _padded(img)
     for k, (x, y) in enumerate(np.asarray(xy, np.float32)):
-        out[k] = interpolate(interp, img, float(x), float(y))
+        out[k] = interpolate(interp, img, float(x), float(y), pad)
     return out
 
 

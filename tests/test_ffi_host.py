@@ -1,0 +1,82 @@
+"""CPU-side checks of the product boundary: the C-ABI library builds for gfx950, loads,
+exports every symbol include/lk_engine.h declares, and refuses to run without a HIP
+device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import correlation_amd as ca
+from correlation_amd import _ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    hdr = open(os.path.join(ROOT, "include", "lk_engine.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(lk_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol(engine_lib):
+    names = declared_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(engine_lib, n), f"{n} declared in lk_engine.h but not exported"
+        assert n in _ffi.SYMBOLS, f"{n} has no ctypes prototype"
+    assert sorted(_ffi.SYMBOLS) == names
+
+
+def test_result_record_layout_matches_reference_struct():
+    # CorrelationResult (domains.hpp:110-118): 6 floats, float, int, int, enum, 2 floats
+    d = ca.RESULT_DTYPE
+    assert d.itemsize == 48
+    assert [d.fields[k][1] for k in ("p", "chi", "n_points", "iterations", "error_code", "und_cx", "und_cy")] == \
+        [0, 24, 28, 32, 36, 40, 44]
+
+
+def test_code_object_is_gfx950(engine_lib):
+    blob = open(ca.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"lk_solve_kernel" in blob and b"lk_pyramid_kernel" in blob
+
+
+def test_create_validates_configuration(engine_lib):
+    h = C.c_void_p()
+    bad = _ffi.LkConfig(2, 9, 1e-3, 50, 0, 1, 2, 0)  # unknown fitting model
+    assert engine_lib.lk_create(C.byref(bad), C.byref(h)) == ca.ERROR_BAD_DOMAIN
+    bad = _ffi.LkConfig(2, 3, 1e-3, 50, 0, 2, 3, 0)  # (stop-start) not a multiple of step
+    assert engine_lib.lk_create(C.byref(bad), C.byref(h)) == ca.ERROR_BAD_DOMAIN
+
+
+def test_fails_loudly_without_a_device(engine_lib):
+    if engine_lib.lk_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(ca.LkError) as ei:
+        ca.HipCorrelationEngine()
+    assert ei.value.code == ca.ERROR_DEVICE
+
+
+def test_missing_library_is_an_import_error(tmp_path):
+    with pytest.raises(ImportError):
+        _ffi.load_library(str(tmp_path / "nope.so"))
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under correlation_amd/, include/ or bench.py's
+    product leg may import, link or open it."""
+    for base in ("correlation_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                    txt = open(os.path.join(dp, f)).read()
+                    assert "lk_oracle" not in txt and "lko_" not in txt and "oracle/" not in txt, \
+                        os.path.join(dp, f)
+
+
+def test_speckle_generator_is_deterministic():
+    a1, b1 = ca.speckle.speckle_pair(96, 128, seed=3)
+    a2, b2 = ca.speckle.speckle_pair(96, 128, seed=3)
+    assert a1.dtype == np.uint8 and a1.shape == (96, 128)
+    assert np.array_equal(a1, a2) and np.array_equal(b1, b2) and not np.array_equal(a1, b1)
