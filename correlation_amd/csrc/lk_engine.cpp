@@ -9,7 +9,7 @@
 //   sector state center[S] (float2), guess[S][6], last_p[S][6], prev_p[S][6],
 //               result[S] (48 B, layout of CorrelationResult), stats[S][4].
 // Everything for an image pair is resident; lk_correlate_all* is one launch per size
-// class (1 / 4 / 8 wavefronts per sector) on one stream.
+// class (16 lanes / 1 / 4 / 8 wavefronts per sector) on one stream.
 #include "lk_device.hpp"
 #include "lk_roi.hpp"
 
@@ -20,8 +20,8 @@
 #include <string>
 #include <vector>
 
-hipError_t lk_launch_solve(const LkSolveArgs &a, int model, int interp, int waves, hipStream_t st);
-hipError_t lk_launch_eval(const LkEvalArgs &a, int model, int interp, hipStream_t st);
+hipError_t lk_launch_solve(const LkSolveArgs &a, int model, int interp, int group, hipStream_t st);
+hipError_t lk_launch_eval(const LkEvalArgs &a, int model, int interp, int group, hipStream_t st);
 hipError_t lk_launch_solve_only(int n, const float *d_in, float *d_out, hipStream_t st);
 hipError_t lk_launch_sample(int interp, const uint8_t *def, int rows, int cols, const float2 *pts, int n,
                             float4 *out, hipStream_t st);
@@ -82,6 +82,12 @@ template <class T> struct DevBuf {
 
 } // namespace
 
+// lanes that own one sector: a 16-lane DPP row (4 sectors per wavefront), one wavefront,
+// or a workgroup of 4 / 8 wavefronts
+static const int kNumClasses = 4;
+static const int kGroupOfClass[kNumClasses] = {16, 64, 256, 512};
+static int size_class(int n0) { return n0 <= 1024 ? 0 : (n0 <= 8192 ? 1 : (n0 <= 65536 ? 2 : 3)); }
+
 struct lk_engine {
   lk_config cfg{};
   int P = 0;
@@ -109,7 +115,8 @@ struct lk_engine {
   DevBuf<uint32_t> d_stats;
   DevBuf<uint32_t> d_order;
   std::vector<uint32_t> h_order; // sectors grouped by size class
-  int class_begin[4] = {0, 0, 0, 0};
+  int class_begin[kNumClasses + 1] = {0, 0, 0, 0, 0};
+  std::vector<int> h_class; // size class of every sector
   DevBuf<uint32_t> d_single;
   DevBuf<float> d_scratch; // 64 floats for the stand-alone entry points
   DevBuf<float2> d_warp;
@@ -132,9 +139,6 @@ struct lk_engine {
     if (_e != hipSuccess)                                                                             \
       return e->hipfail(_e, #call);                                                                   \
   } while (0)
-
-static const int kWavesOfClass[3] = {1, 4, 8};
-static int size_class(int n0) { return n0 <= 2048 ? 0 : (n0 <= 32768 ? 1 : 2); }
 
 extern "C" {
 
@@ -539,16 +543,39 @@ int lk_commit_sectors(lk_engine *e) {
   HIPCHK(hipMemset(e->d_last_p.p, 0, 6 * (size_t)S * sizeof(float)));
   HIPCHK(hipMemset(e->d_prev_p.p, 0, 6 * (size_t)S * sizeof(float)));
   HIPCHK(hipMemset(e->d_stats.p, 0, 4 * (size_t)S * sizeof(uint32_t)));
-  // size classes -> wavefronts per sector
+  // size classes -> lanes per sector.  A class whose sectors are too few to fill the chip
+  // (< 2048 wavefronts) and still large per lane is promoted to the next wider group.
+  e->h_class.assign((size_t)S, 0);
+  size_t cnt[kNumClasses] = {0, 0, 0, 0}, tot[kNumClasses] = {0, 0, 0, 0};
+  for (int s = 0; s < S; ++s) {
+    int n0 = (int)(e->hs[(size_t)s].xy.size() / 2), c = size_class(n0);
+    e->h_class[(size_t)s] = c;
+    cnt[c]++;
+    tot[c] += (size_t)n0;
+  }
+  for (int c = 0; c + 1 < kNumClasses; ++c) {
+    if (!cnt[c])
+      continue;
+    size_t waves = cnt[c] * (size_t)kGroupOfClass[c] / 64;
+    size_t per_lane = tot[c] / cnt[c] / (size_t)kGroupOfClass[c];
+    if (waves < 2048 && per_lane >= 32) {
+      for (int s = 0; s < S; ++s)
+        if (e->h_class[(size_t)s] == c)
+          e->h_class[(size_t)s] = c + 1;
+      cnt[c + 1] += cnt[c];
+      tot[c + 1] += tot[c];
+      cnt[c] = tot[c] = 0;
+    }
+  }
   e->h_order.clear();
   e->h_order.reserve((size_t)S);
-  for (int c = 0; c < 3; ++c) {
+  for (int c = 0; c < kNumClasses; ++c) {
     e->class_begin[c] = (int)e->h_order.size();
     for (int s = 0; s < S; ++s)
-      if (size_class((int)(e->hs[(size_t)s].xy.size() / 2)) == c)
+      if (e->h_class[(size_t)s] == c)
         e->h_order.push_back((uint32_t)s);
   }
-  e->class_begin[3] = (int)e->h_order.size();
+  e->class_begin[kNumClasses] = (int)e->h_order.size();
   HIPCHK(e->d_order.ensure((size_t)S));
   HIPCHK(hipMemcpy(e->d_order.p, e->h_order.data(), (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice));
   HIPCHK(e->d_single.ensure(1));
@@ -677,17 +704,23 @@ static LkSolveArgs base_args(lk_engine *e, const float *d_guess, lk_result *d_re
   return a;
 }
 
+static void set_grid(LkSolveArgs &a, int n, int group) {
+  const int per_wg = group < 64 ? 64 / group : 1; // sectors per workgroup
+  const int n_wg = (n + per_wg - 1) / per_wg;
+  a.n_sectors = n;
+  a.chunk = (n_wg + 7) / 8;
+}
+
 static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
   HIPCHK(hipEventRecord(e->ev_s0, e->stream));
-  for (int c = 0; c < 3; ++c) {
+  for (int c = 0; c < kNumClasses; ++c) {
     int n = e->class_begin[c + 1] - e->class_begin[c];
     if (n <= 0)
       continue;
     LkSolveArgs a = base_args(e, d_guess, d_result);
     a.order = e->d_order.p + e->class_begin[c];
-    a.n_sectors = n;
-    a.chunk = (n + 7) / 8;
-    HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, kWavesOfClass[c], e->stream));
+    set_grid(a, n, kGroupOfClass[c]);
+    HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, kGroupOfClass[c], e->stream));
   }
   HIPCHK(hipEventRecord(e->ev_s1, e->stream));
   e->solve_timed = true;
@@ -748,12 +781,10 @@ int lk_correlate(lk_engine *e, int sector, float *guess_inout, lk_result *out) {
   HIPCHK(hipStreamSynchronize(e->stream));
   LkSolveArgs a = base_args(e, e->d_guess.p, e->d_result.p);
   a.order = e->d_single.p;
-  a.n_sectors = 1;
-  a.chunk = 1;
-  int n0 = (int)(e->h_off[0][(size_t)sector + 1] - e->h_off[0][(size_t)sector]);
+  const int group = kGroupOfClass[e->h_class[(size_t)sector]];
+  set_grid(a, 1, group);
   HIPCHK(hipEventRecord(e->ev_s0, e->stream));
-  HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, kWavesOfClass[size_class(n0)],
-                         e->stream));
+  HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, group, e->stream));
   HIPCHK(hipEventRecord(e->ev_s1, e->stream));
   e->solve_timed = true;
   e->stats_valid = false;
@@ -811,7 +842,8 @@ int lk_evaluate(lk_engine *e, int sector, int level, const float *p, float *A36,
   for (int i = 0; i < 6; ++i)
     a.p[i] = i < e->P ? p[i] : 0.f;
   a.out = e->d_scratch.p;
-  HIPCHK(lk_launch_eval(a, e->cfg.fitting_model, e->cfg.interpolation, e->stream));
+  HIPCHK(lk_launch_eval(a, e->cfg.fitting_model, e->cfg.interpolation,
+                        kGroupOfClass[e->h_class[(size_t)sector]], e->stream));
   float h[44];
   HIPCHK(hipMemcpyAsync(h, e->d_scratch.p, sizeof(h), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));

@@ -1,6 +1,6 @@
 // lk_kernels.hip - hand-written CDNA4 (gfx950) kernels of the Lucas-Kanade engine.
 //
-//   lk_solve_kernel    one workgroup (1, 4 or 8 wavefronts) owns one sector for its
+//   lk_solve_kernel    one lane group (a 16-lane DPP row, a wavefront, or 4/8 wavefronts) owns one sector for its
 //                      whole coarse-to-fine Levenberg-Marquardt solve: warp -> bicubic
 //                      sample of the deformed image + gradient -> residual -> per-lane
 //                      accumulation of the 21+6+1 sums -> DPP wavefront reduction ->
@@ -28,6 +28,11 @@ namespace {
 
 constexpr int kWave = 64;
 
+// pointers that are known to be global memory (loaded from a struct they would be
+// generic and cost flat_load instead of global_load)
+template <class T> using gptr = const __attribute__((address_space(1))) T *;
+typedef float f32x2 __attribute__((ext_vector_type(2))); // same layout as float2
+
 __host__ __device__ constexpr int n_params(int model) {
   return model == LK_FM_U ? 1 : model == LK_FM_UV ? 2 : model == LK_FM_UVQ ? 3 : 6;
 }
@@ -41,21 +46,10 @@ template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
   return v + __int_as_float(t);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-  v = dpp_add<0xB1>(v);  // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E>(v);  // quad_perm [2,3,0,1]
-  v = dpp_add<0x141>(v); // row_half_mirror
-  v = dpp_add<0x140>(v); // row_mirror
-  float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-  float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-  float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-  float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-  return (r0 + r1) + (r2 + r3);
-}
-
-__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) {
+__device__ __forceinline__ uint32_t load_u32_unaligned(gptr<uint8_t> p) {
   uint32_t v;
-  __builtin_memcpy(&v, p, 4);
+  typedef uint32_t __attribute__((aligned(1))) u32_u;
+  v = *(const __attribute__((address_space(1))) u32_u *)p;
   return v;
 }
 
@@ -84,9 +78,9 @@ __device__ __forceinline__ void cubic_1d(float p0, float p1, float p2, float p3,
 }
 
 // a[4*jk+ik]; def points at the level's image, pitch = cols
-__device__ __forceinline__ void bicubic_coeffs(const uint8_t *def, int cols, int ix, int iy,
+__device__ __forceinline__ void bicubic_coeffs(gptr<uint8_t> def, int cols, int ix, int iy,
                                                float (&a)[16]) {
-  const uint8_t *base = def + (size_t)(iy - 1) * (size_t)cols + (size_t)(ix - 1);
+  gptr<uint8_t> base = def + (size_t)(iy - 1) * (size_t)cols + (size_t)(ix - 1);
   uint32_t r0 = load_u32_unaligned(base);
   uint32_t r1 = load_u32_unaligned(base + cols);
   uint32_t r2 = load_u32_unaligned(base + 2 * (size_t)cols);
@@ -127,7 +121,7 @@ __device__ __forceinline__ void bicubic_eval(const float (&a)[16], float dx, flo
 
 // returns false when the sample leaves the image (error_interpolation_out_of_image)
 template <int INTERP>
-__device__ __forceinline__ bool sample_def(const uint8_t *def, int rows, int cols, float xd,
+__device__ __forceinline__ bool sample_def(gptr<uint8_t> def, int rows, int cols, float xd,
                                            float yd, float &W, float &Wx, float &Wy) {
   if constexpr (INTERP == LK_IM_BICUBIC) {
     if (!(xd > 1.f && yd > 1.f && xd < (float)cols - 2.f && yd < (float)rows - 2.f))
@@ -142,7 +136,7 @@ __device__ __forceinline__ bool sample_def(const uint8_t *def, int rows, int col
     if (!(xd > 0.f && yd > 0.f && xd < (float)(cols - 1) && yd < (float)(rows - 1)))
       return false;
     int ix = (int)xd, iy = (int)yd;
-    const uint8_t *q = def + (size_t)iy * (size_t)cols + (size_t)ix;
+    gptr<uint8_t> q = def + (size_t)iy * (size_t)cols + (size_t)ix;
     float w00 = (float)q[0], w10 = (float)q[1], w01 = (float)q[cols], w11 = (float)q[cols + 1];
     float a0 = w00, a1 = w10 - w00, a2 = w01 - w00, a3 = w11 - w10 - w01 + w00;
     float dx = xd - (float)ix, dy = yd - (float)iy;
@@ -160,7 +154,7 @@ __device__ __forceinline__ bool sample_def(const uint8_t *def, int rows, int col
     if (!(xd > 0.f && yd > 0.f && xd < (float)(cols - 1) && yd < (float)(rows - 1)))
       return false;
     int ix = (int)(xd + 0.5f), iy = (int)(yd + 0.5f);
-    const uint8_t *q = def + (size_t)iy * (size_t)cols + (size_t)ix;
+    gptr<uint8_t> q = def + (size_t)iy * (size_t)cols + (size_t)ix;
     float w00 = (float)q[0], w10 = (float)q[1], w01 = (float)q[cols];
     W = w00;
     Wx = w10 - w00;
@@ -234,32 +228,56 @@ template <int P> struct Sums { // upper triangle row-major, then b, then chi
   float v[N];
 };
 
-// One evaluation of one sector at one level by the whole workgroup
-// (apply_model_and_interpolate, correlation_class.cpp:131-300).  On return every thread
-// holds the same totals; returns the error flag (any sample out of the image).
-template <int MODEL, int INTERP, int WAVES>
-__device__ __forceinline__ bool evaluate(const LkLevelView &lv, uint32_t off, int n, float cx,
-                                         float cy, const float (&p)[6], Sums<n_params(MODEL)> &S,
-                                         float *lds) {
+// One evaluation of one sector at one level by its lane group
+// (apply_model_and_interpolate, correlation_class.cpp:131-300).  A "group" is the set of
+// lanes that owns one sector: a 16-lane DPP row (4 sectors per wavefront), a whole
+// wavefront, or a whole workgroup.  On return every lane of the group holds the same
+// totals; returns the error flag (some sample of the group's sector left the image).
+struct LevelCtx { // what a lane needs to know about its sector at the current level
+  gptr<uint8_t> und, def;
+  gptr<f32x2> xy;  // already offset to the sector's first sample
+  int n;
+  int urows, ucols, drows, dcols;
+  float cx, cy, scaling;
+};
+
+// sum inside each 16-lane row: every lane of the row ends with the same bits
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);  // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);  // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v); // row_half_mirror
+  v = dpp_add<0x140>(v); // row_mirror
+  return v;
+}
+
+__device__ __forceinline__ float rows_sum(float v) { // after row16_sum: add the 4 rows
+  float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
+template <int MODEL, int INTERP, int GROUP, int THREADS>
+__device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
+                                         Sums<n_params(MODEL)> &S, float *lds) {
   constexpr int P = n_params(MODEL);
   using SumsT = Sums<P>;
-  constexpr int T = WAVES * kWave;
 #pragma unroll
   for (int i = 0; i < SumsT::N; ++i)
     S.v[i] = 0.f;
   bool bad = false;
-  const float2 *xy = lv.xy + off;
-  const int ucols = lv.ucols, umaxr = lv.urows - 1, umaxc = lv.ucols - 1;
-  for (int k = (int)threadIdx.x; k < n; k += T) {
-    float2 q = xy[k];
+  const int umaxr = c.urows - 1, umaxc = c.ucols - 1;
+  for (int k = (int)threadIdx.x % GROUP; k < c.n; k += GROUP) {
+    const f32x2 q = c.xy[k];
     float xd, yd, dx = 0.f, dy = 0.f;
-    Warp<MODEL>::apply(q.x, q.y, cx, cy, p, xd, yd, dx, dy);
+    Warp<MODEL>::apply(q.x, q.y, c.cx, c.cy, p, xd, yd, dx, dy);
     int uix = (int)(q.x + 0.5f), uiy = (int)(q.y + 0.5f);
     uix = min(max(uix, 0), umaxc); // memory safety only; valid sample lists never clamp
     uiy = min(max(uiy, 0), umaxr);
-    float und_w = (float)lv.und[(size_t)uiy * (size_t)ucols + (size_t)uix];
+    float und_w = (float)c.und[(size_t)uiy * (size_t)c.ucols + (size_t)uix];
     float W, Wx, Wy;
-    if (!sample_def<INTERP>(lv.def, lv.drows, lv.dcols, xd, yd, W, Wx, Wy)) {
+    if (!sample_def<INTERP>(c.def, c.drows, c.dcols, xd, yd, W, Wx, Wy)) {
       bad = true;
       continue; // the sums of an evaluation that hit the error are never used
     }
@@ -280,32 +298,42 @@ __device__ __forceinline__ bool evaluate(const LkLevelView &lv, uint32_t off, in
   // reconverged: all 64 lanes of every wave are active from here on
 #pragma unroll
   for (int i = 0; i < SumsT::N; ++i)
-    S.v[i] = wave_sum(S.v[i]);
-  bool any_bad = __ballot(bad) != 0ull;
-  if constexpr (WAVES > 1) {
-    const int wave = (int)threadIdx.x / kWave, lane = (int)threadIdx.x % kWave;
-    constexpr int STRIDE = SumsT::N + 1;
-    __syncthreads(); // previous readers of lds are done
-    if (lane == 0) {
+    S.v[i] = row16_sum(S.v[i]);
+  const unsigned long long badmask = __ballot(bad);
+  if constexpr (GROUP == 16) {
+    const int row = ((int)threadIdx.x & 63) >> 4;
+    return ((badmask >> (16 * row)) & 0xffffull) != 0ull;
+  } else {
 #pragma unroll
-      for (int i = 0; i < SumsT::N; ++i)
-        lds[wave * STRIDE + i] = S.v[i];
-      lds[wave * STRIDE + SumsT::N] = any_bad ? 1.f : 0.f;
-    }
-    __syncthreads();
+    for (int i = 0; i < SumsT::N; ++i)
+      S.v[i] = rows_sum(S.v[i]);
+    bool any_bad = badmask != 0ull;
+    if constexpr (GROUP > kWave) {
+      constexpr int WAVES = THREADS / kWave;
+      const int wave = (int)threadIdx.x / kWave, lane = (int)threadIdx.x % kWave;
+      constexpr int STRIDE = SumsT::N + 1;
+      __syncthreads(); // previous readers of lds are done
+      if (lane == 0) {
 #pragma unroll
-    for (int i = 0; i < SumsT::N; ++i) {
-      float t = lds[i];
-      for (int w = 1; w < WAVES; ++w)
-        t += lds[w * STRIDE + i];
-      S.v[i] = t;
+        for (int i = 0; i < SumsT::N; ++i)
+          lds[wave * STRIDE + i] = S.v[i];
+        lds[wave * STRIDE + SumsT::N] = any_bad ? 1.f : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < SumsT::N; ++i) {
+        float t = lds[i];
+        for (int w = 1; w < WAVES; ++w)
+          t += lds[w * STRIDE + i];
+        S.v[i] = t;
+      }
+      float eb = 0.f;
+      for (int w = 0; w < WAVES; ++w)
+        eb += lds[w * STRIDE + SumsT::N];
+      any_bad = eb != 0.f;
     }
-    float eb = 0.f;
-    for (int w = 0; w < WAVES; ++w)
-      eb += lds[w * STRIDE + SumsT::N];
-    any_bad = eb != 0.f;
+    return any_bad;
   }
-  return any_bad;
 }
 
 // ------------------------------------------------------------------------------------
@@ -523,135 +551,175 @@ template <int P> __device__ __forceinline__ void translate(float (&p)[6], int sr
 // ------------------------------------------------------------------------------------
 // the solve kernel: CorrelationClass::Newton_Raphson (correlation_class.cpp:349-640)
 // ------------------------------------------------------------------------------------
-template <int MODEL, int INTERP, int WAVES>
-__global__ void __launch_bounds__(WAVES *kWave) lk_solve_kernel(LkSolveArgs a) {
+// The reference's nested loops (levels x LM trips, one or two evaluations per trip) are
+// flattened into a per-sector state machine that performs exactly ONE evaluation + ONE
+// damped solve per step, so that the lane groups of a wavefront (GROUP = 16: four sectors
+// per wavefront, each on its own DPP row) can be at different points of their own
+// trajectories while sharing the instruction stream:
+//   EVAL0   evaluation #0 of a level (:410-437)
+//   TENT    evaluation of the tentative parameters + look-ahead solve (:503-529)
+//   REEVAL  reject path: re-evaluate at last_good with the larger lambda (:475-499)
+// GROUP == THREADS (64, 256, 512): one sector per workgroup, control flow is uniform.
+enum : int { PH_EVAL0 = 0, PH_TENT = 1, PH_REEVAL = 2, PH_DONE = 3 };
+
+template <int MODEL, int INTERP, int GROUP, int THREADS>
+__global__ void __launch_bounds__(THREADS) lk_solve_kernel(LkSolveArgs a) {
   constexpr int P = n_params(MODEL);
   using SumsT = Sums<P>;
-  __shared__ float lds[WAVES > 1 ? WAVES * (SumsT::N + 1) : 1];
+  constexpr int SECTORS_PER_WG = THREADS / GROUP;
+  __shared__ float lds[GROUP > kWave ? (THREADS / kWave) * (SumsT::N + 1) : 1];
 
   // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs, so give each
   // XCD one contiguous run of sectors (neighbouring sectors share image rows in its L2).
   const int b = (int)blockIdx.x;
-  int slot = (b & 7) * a.chunk + (b >> 3);
-  if (slot >= a.n_sectors)
+  const int wg_slot = (b & 7) * a.chunk + (b >> 3);
+  if (wg_slot * SECTORS_PER_WG >= a.n_sectors)
     return;
-  const int s = a.order ? (int)a.order[slot] : slot;
+  const int slot = wg_slot * SECTORS_PER_WG + (int)threadIdx.x / GROUP;
+  const bool valid = slot < a.n_sectors;
+  const int s = valid ? (a.order ? (int)a.order[slot] : slot) : 0;
 
-  float p[6], lg_p[6], tent[6], saved[6];
+  float p[6], lg_p[6], tent[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    p[i] = i < P ? a.guess[(size_t)s * 6 + i] : 0.f;
-    lg_p[i] = tent[i] = saved[i] = 0.f;
+    p[i] = (i < P && valid) ? a.guess[(size_t)s * 6 + i] : 0.f;
+    lg_p[i] = tent[i] = 0.f;
   }
   const float2 c0 = a.center[s];
   const float min_lambda = 1e-9f, max_lambda = 1e9f;
-  float last_good_chi = FLT_MAX;
-  int reached_iterations = 0;
+  float last_good_chi = FLT_MAX, lambda = 0.0001f;
+  int reached_iterations = 0, iteration = 0;
   int error_code = LK_ERROR_NONE;
   uint32_t n_evals = 0, n_sample_evals = 0, n_point_iters = 0;
-  int level_old = 0;
-  bool early = false;
+  int level = a.py_stop, level_old = 0;
+  bool use_saved = true;
+  int phase = valid ? PH_EVAL0 : PH_DONE;
+  LevelCtx c{};
   SumsT S;
 
-  for (int level = a.py_stop; level >= a.py_start; level -= a.py_step) {
+  auto enter_level = [&]() { // top of the level loop (:373-408)
     const LkLevelView lv = a.lv[level];
     translate<P>(p, level_old, level);
     error_code = LK_ERROR_NONE;
-    float lambda = 0.0001f;
+    lambda = 0.0001f;
     last_good_chi = FLT_MAX;
     const uint32_t off = lv.off[s];
-    const int n = (int)(lv.off[s + 1] - off);
-    const float scaling = 1.f / ((float)n);
+    c.n = (int)(lv.off[s + 1] - off);
+    c.und = (gptr<uint8_t>)lv.und;
+    c.def = (gptr<uint8_t>)lv.def;
+    c.xy = (gptr<f32x2>)(lv.xy + off);
+    c.urows = lv.urows;
+    c.ucols = lv.ucols;
+    c.drows = lv.drows;
+    c.dcols = lv.dcols;
+    c.scaling = 1.f / ((float)c.n);
     const float inv = 1.f / (float)(1 << level); // pyramid_class.cpp:357-361
-    const float cx = level == 0 ? c0.x : c0.x * inv, cy = level == 0 ? c0.y : c0.y * inv;
+    c.cx = level == 0 ? c0.x : c0.x * inv;
+    c.cy = level == 0 ? c0.y : c0.y * inv;
 #pragma unroll
     for (int i = 0; i < P; ++i)
       lg_p[i] = p[i];
+    phase = PH_EVAL0;
+  };
+  if (valid)
+    enter_level();
 
-    // evaluation #0 (:410-437)
-    bool err = evaluate<MODEL, INTERP, WAVES>(lv, off, n, cx, cy, p, S, lds);
-    ++n_evals;
-    n_sample_evals += (uint32_t)n;
-    ++n_point_iters;
-    if (err) {
-      error_code = LK_ERROR_INTERPOLATION_OUT_OF_IMAGE;
-      translate<P>(p, level, 0);
-      early = true;
-      break;
+  for (;;) {
+    const bool active = phase != PH_DONE;
+    if constexpr (GROUP >= kWave) {
+      if (!active)
+        break; // uniform over the workgroup
+    } else {
+      if (__ballot(active) == 0ull)
+        break; // every sector of this wavefront is finished
     }
-    float chi = S.v[SumsT::N - 1] * scaling;
-    last_good_chi = chi;
-    damped_step<P>(S, lambda, scaling, p);
-#pragma unroll
-    for (int i = 0; i < P; ++i)
-      saved[i] = p[i];
-    bool use_saved = true;
-
-    for (int iteration = 1; iteration <= a.max_iters + 1; ++iteration) {
-      if (iteration > a.max_iters || lambda >= max_lambda) {
-        error_code = LK_ERROR_CORRELATION_MAX_ITERS_REACHED;
-        break;
-      }
-      reached_iterations = iteration;
-      ++n_point_iters;
-      if (use_saved) {
-#pragma unroll
-        for (int i = 0; i < P; ++i)
-          tent[i] = saved[i];
-      } else { // reject path: re-evaluate at last_good with the larger lambda (:475-499)
-#pragma unroll
-        for (int i = 0; i < P; ++i)
-          p[i] = lg_p[i];
-        err = evaluate<MODEL, INTERP, WAVES>(lv, off, n, cx, cy, p, S, lds);
-        ++n_evals;
-        n_sample_evals += (uint32_t)n;
-        if (err) {
-          error_code = LK_ERROR_INTERPOLATION_OUT_OF_IMAGE;
-          break;
-        }
-        damped_step<P>(S, lambda, scaling, p);
-#pragma unroll
-        for (int i = 0; i < P; ++i)
-          tent[i] = p[i];
-      }
-#pragma unroll
-      for (int i = 0; i < P; ++i)
-        p[i] = tent[i];
-      err = evaluate<MODEL, INTERP, WAVES>(lv, off, n, cx, cy, p, S, lds);
+    LevelCtx ce = c;
+    if (!active)
+      ce.n = 0;
+    const bool err = evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds);
+    if (active) {
       ++n_evals;
-      n_sample_evals += (uint32_t)n;
-      chi = S.v[SumsT::N - 1] * scaling;
-      if (err) {
+      n_sample_evals += (uint32_t)c.n;
+      bool level_end = false, iter_start = false;
+      if (err) { // :413-419 (evaluation #0: return at once), :484-489, :511-516 (break)
         error_code = LK_ERROR_INTERPOLATION_OUT_OF_IMAGE;
-        break;
-      }
-      // look-ahead step with the next lambda (:523-529)
-      damped_step<P>(S, fmaxf(lambda * 0.4f, min_lambda), scaling, p);
-#pragma unroll
-      for (int i = 0; i < P; ++i)
-        saved[i] = p[i];
-      float delta_chi =
-          __builtin_fabsf((last_good_chi - chi) / (fmaxf(last_good_chi, chi) + a.precision));
-      if (chi <= last_good_chi) {
-        last_good_chi = chi;
-        lambda = fmaxf(lambda * 0.4f, min_lambda);
-#pragma unroll
-        for (int i = 0; i < P; ++i)
-          lg_p[i] = tent[i];
-        use_saved = true;
+        if (phase == PH_EVAL0) {
+          ++n_point_iters;
+          translate<P>(p, level, 0);
+          phase = PH_DONE;
+        } else {
+          level_end = true;
+        }
       } else {
-        lambda = fminf(lambda * 10.0f, max_lambda);
-        use_saved = false;
+        const float chi = S.v[SumsT::N - 1] * c.scaling;
+        const float lam_use = phase == PH_TENT ? fmaxf(lambda * 0.4f, min_lambda) : lambda;
+        if (phase == PH_TENT) {
+#pragma unroll
+          for (int i = 0; i < P; ++i)
+            tent[i] = p[i];
+        }
+        damped_step<P>(S, lam_use, c.scaling, p); // p += dp (compute_model_parameters)
+        if (phase == PH_EVAL0) {
+          ++n_point_iters;
+          last_good_chi = chi;
+          use_saved = true;
+          iteration = 1;
+          iter_start = true;
+        } else if (phase == PH_REEVAL) {
+          phase = PH_TENT; // p now holds the tentative parameters
+        } else {           // PH_TENT: p now holds the look-ahead ("saved") parameters
+          const float delta_chi =
+              __builtin_fabsf((last_good_chi - chi) / (fmaxf(last_good_chi, chi) + a.precision));
+          if (chi <= last_good_chi) {
+            last_good_chi = chi;
+            lambda = fmaxf(lambda * 0.4f, min_lambda);
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+              lg_p[i] = tent[i];
+            use_saved = true;
+          } else {
+            lambda = fminf(lambda * 10.0f, max_lambda);
+            use_saved = false;
+          }
+          if (delta_chi < a.precision) {
+            level_end = true;
+          } else {
+            ++iteration;
+            iter_start = true;
+          }
+        }
       }
-      if (delta_chi < a.precision)
-        break;
+      if (iter_start) { // top of the iteration loop (:441-499)
+        if (iteration > a.max_iters || lambda >= max_lambda) {
+          error_code = LK_ERROR_CORRELATION_MAX_ITERS_REACHED;
+          level_end = true;
+        } else {
+          reached_iterations = iteration;
+          ++n_point_iters;
+          if (use_saved) {
+            phase = PH_TENT; // tentative = saved = p
+          } else {
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+              p[i] = lg_p[i];
+            phase = PH_REEVAL;
+          }
+        }
+      }
+      if (level_end) { // :589-591, :638
+        level_old = level;
+        level -= a.py_step;
+        if (level < a.py_start) {
+          translate<P>(p, level_old, 0);
+          phase = PH_DONE;
+        } else {
+          enter_level();
+        }
+      }
     }
-    level_old = level;
   }
-  if (!early)
-    translate<P>(p, level_old, 0);
 
-  if (threadIdx.x == 0) {
+  if ((int)threadIdx.x % GROUP == 0 && valid) {
     lk_result r;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -678,23 +746,34 @@ __global__ void __launch_bounds__(WAVES *kWave) lk_solve_kernel(LkSolveArgs a) {
 }
 
 // stand-alone evaluation of one sector/level (known-answer tests): same evaluate<>()
-template <int MODEL, int INTERP, int WAVES>
-__global__ void __launch_bounds__(WAVES *kWave) lk_eval_kernel(LkEvalArgs a) {
+template <int MODEL, int INTERP, int GROUP>
+__global__ void __launch_bounds__(256) lk_eval_kernel(LkEvalArgs a) {
   constexpr int P = n_params(MODEL);
   using SumsT = Sums<P>;
-  __shared__ float lds[WAVES > 1 ? WAVES * (SumsT::N + 1) : 1];
+  __shared__ float lds[4 * (SumsT::N + 1)];
   const LkLevelView lv = a.lv[a.level];
   const uint32_t off = lv.off[a.sector];
-  const int n = (int)(lv.off[a.sector + 1] - off);
   const float2 c0 = a.center[a.sector];
   const float inv = 1.f / (float)(1 << a.level);
-  const float cx = a.level == 0 ? c0.x : c0.x * inv, cy = a.level == 0 ? c0.y : c0.y * inv;
+  LevelCtx c{};
+  c.n = (int)(lv.off[a.sector + 1] - off);
+  if (GROUP == 16 && (int)threadIdx.x >= 16)
+    c.n = 0; // only the first row owns the sector; the other groups idle
+  c.und = (gptr<uint8_t>)lv.und;
+  c.def = (gptr<uint8_t>)lv.def;
+  c.xy = (gptr<f32x2>)(lv.xy + off);
+  c.urows = lv.urows;
+  c.ucols = lv.ucols;
+  c.drows = lv.drows;
+  c.dcols = lv.dcols;
+  c.cx = a.level == 0 ? c0.x : c0.x * inv;
+  c.cy = a.level == 0 ? c0.y : c0.y * inv;
   float p[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i)
     p[i] = a.p[i];
   SumsT S;
-  bool err = evaluate<MODEL, INTERP, WAVES>(lv, off, n, cx, cy, p, S, lds);
+  bool err = evaluate<MODEL, INTERP, GROUP, 256>(c, p, S, lds);
   if (threadIdx.x == 0) {
     for (int i = 0; i < 44; ++i)
       a.out[i] = 0.f;
@@ -718,7 +797,7 @@ __global__ void lk_sample_kernel(const uint8_t *def, int rows, int cols, const f
   if (k >= n)
     return;
   float W = 0.f, Wx = 0.f, Wy = 0.f;
-  bool ok = sample_def<INTERP>(def, rows, cols, pts[k].x, pts[k].y, W, Wx, Wy);
+  bool ok = sample_def<INTERP>((gptr<uint8_t>)def, rows, cols, pts[k].x, pts[k].y, W, Wx, Wy);
   out[k] = ok ? make_float4(W, Wx, Wy, 0.f) : make_float4(0.f, 0.f, 0.f, 1.f);
 }
 
@@ -859,52 +938,62 @@ __global__ void lk_warp_points_kernel(const float2 *xy, int n, float cx, float c
 // launch wrappers (called from lk_engine.cpp)
 // ------------------------------------------------------------------------------------
 template <int MODEL, int INTERP>
-static hipError_t launch_solve_mi(const LkSolveArgs &a, int waves, hipStream_t st) {
+static hipError_t launch_solve_mi(const LkSolveArgs &a, int group, hipStream_t st) {
   dim3 grid((unsigned)(a.chunk * 8));
-  switch (waves) {
-  case 1: hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, 1>), grid, dim3(64), 0, st, a); break;
-  case 4: hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, 4>), grid, dim3(256), 0, st, a); break;
-  default: hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, 8>), grid, dim3(512), 0, st, a); break;
+  switch (group) {
+  case 16: hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, 16, 64>), grid, dim3(64), 0, st, a); break;
+  case 64: hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, 64, 64>), grid, dim3(64), 0, st, a); break;
+  case 256: hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, 256, 256>), grid, dim3(256), 0, st, a); break;
+  default: hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, 512, 512>), grid, dim3(512), 0, st, a); break;
   }
   return hipGetLastError();
 }
 
 template <int MODEL>
-static hipError_t launch_solve_m(const LkSolveArgs &a, int interp, int waves, hipStream_t st) {
+static hipError_t launch_solve_m(const LkSolveArgs &a, int interp, int group, hipStream_t st) {
   switch (interp) {
-  case LK_IM_NEAREST: return launch_solve_mi<MODEL, LK_IM_NEAREST>(a, waves, st);
-  case LK_IM_BILINEAR: return launch_solve_mi<MODEL, LK_IM_BILINEAR>(a, waves, st);
-  default: return launch_solve_mi<MODEL, LK_IM_BICUBIC>(a, waves, st);
+  case LK_IM_NEAREST: return launch_solve_mi<MODEL, LK_IM_NEAREST>(a, group, st);
+  case LK_IM_BILINEAR: return launch_solve_mi<MODEL, LK_IM_BILINEAR>(a, group, st);
+  default: return launch_solve_mi<MODEL, LK_IM_BICUBIC>(a, group, st);
   }
 }
 
-hipError_t lk_launch_solve(const LkSolveArgs &a, int model, int interp, int waves, hipStream_t st) {
+hipError_t lk_launch_solve(const LkSolveArgs &a, int model, int interp, int group, hipStream_t st) {
   if (a.n_sectors <= 0)
     return hipSuccess;
   switch (model) {
-  case LK_FM_U: return launch_solve_m<LK_FM_U>(a, interp, waves, st);
-  case LK_FM_UV: return launch_solve_m<LK_FM_UV>(a, interp, waves, st);
-  case LK_FM_UVQ: return launch_solve_m<LK_FM_UVQ>(a, interp, waves, st);
-  default: return launch_solve_m<LK_FM_UVUXUYVXVY>(a, interp, waves, st);
+  case LK_FM_U: return launch_solve_m<LK_FM_U>(a, interp, group, st);
+  case LK_FM_UV: return launch_solve_m<LK_FM_UV>(a, interp, group, st);
+  case LK_FM_UVQ: return launch_solve_m<LK_FM_UVQ>(a, interp, group, st);
+  default: return launch_solve_m<LK_FM_UVUXUYVXVY>(a, interp, group, st);
   }
 }
 
-template <int MODEL>
-static hipError_t launch_eval_m(const LkEvalArgs &a, int interp, hipStream_t st) {
+template <int MODEL, int GROUP>
+static hipError_t launch_eval_mg(const LkEvalArgs &a, int interp, hipStream_t st) {
   switch (interp) {
-  case LK_IM_NEAREST: hipLaunchKernelGGL((lk_eval_kernel<MODEL, LK_IM_NEAREST, 4>), dim3(1), dim3(256), 0, st, a); break;
-  case LK_IM_BILINEAR: hipLaunchKernelGGL((lk_eval_kernel<MODEL, LK_IM_BILINEAR, 4>), dim3(1), dim3(256), 0, st, a); break;
-  default: hipLaunchKernelGGL((lk_eval_kernel<MODEL, LK_IM_BICUBIC, 4>), dim3(1), dim3(256), 0, st, a); break;
+  case LK_IM_NEAREST: hipLaunchKernelGGL((lk_eval_kernel<MODEL, LK_IM_NEAREST, GROUP>), dim3(1), dim3(256), 0, st, a); break;
+  case LK_IM_BILINEAR: hipLaunchKernelGGL((lk_eval_kernel<MODEL, LK_IM_BILINEAR, GROUP>), dim3(1), dim3(256), 0, st, a); break;
+  default: hipLaunchKernelGGL((lk_eval_kernel<MODEL, LK_IM_BICUBIC, GROUP>), dim3(1), dim3(256), 0, st, a); break;
   }
   return hipGetLastError();
 }
 
-hipError_t lk_launch_eval(const LkEvalArgs &a, int model, int interp, hipStream_t st) {
+template <int MODEL>
+static hipError_t launch_eval_m(const LkEvalArgs &a, int interp, int group, hipStream_t st) {
+  switch (group) {
+  case 16: return launch_eval_mg<MODEL, 16>(a, interp, st);
+  case 64: return launch_eval_mg<MODEL, 64>(a, interp, st);
+  default: return launch_eval_mg<MODEL, 256>(a, interp, st);
+  }
+}
+
+hipError_t lk_launch_eval(const LkEvalArgs &a, int model, int interp, int group, hipStream_t st) {
   switch (model) {
-  case LK_FM_U: return launch_eval_m<LK_FM_U>(a, interp, st);
-  case LK_FM_UV: return launch_eval_m<LK_FM_UV>(a, interp, st);
-  case LK_FM_UVQ: return launch_eval_m<LK_FM_UVQ>(a, interp, st);
-  default: return launch_eval_m<LK_FM_UVUXUYVXVY>(a, interp, st);
+  case LK_FM_U: return launch_eval_m<LK_FM_U>(a, interp, group, st);
+  case LK_FM_UV: return launch_eval_m<LK_FM_UV>(a, interp, group, st);
+  case LK_FM_UVQ: return launch_eval_m<LK_FM_UVQ>(a, interp, group, st);
+  default: return launch_eval_m<LK_FM_UVUXUYVXVY>(a, interp, group, st);
   }
 }
 
