@@ -12,6 +12,10 @@ struct LkLevelView {
   const uint8_t *def;  // deformed image, level L
   const float2 *xy;    // concatenated per-sector sample lists of level L (AoS x,y)
   const uint32_t *off; // [S+1] start of each sector's list in xy
+  const int4 *rect;    // [S] implicit rectangular sectors: {x_first, y_first, width, n} at this
+                       //     level (the same sample SET as manager_class.cpp:1607-1611 + the
+                       //     decimation of pyramid_class.cpp:301-322); width == 0 means
+                       //     "use the explicit list"
   int urows, ucols;    // und dims at this level (rows0 >> L, pyramid_class.cpp:447-477)
   int drows, dcols;    // def dims
 };

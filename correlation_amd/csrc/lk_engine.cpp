@@ -52,10 +52,25 @@ struct DevImage {
 };
 
 struct HostSector {
-  std::vector<float> xy; // level-0 AoS
+  std::vector<float> xy; // level-0 AoS (empty for rectangular sectors: generated on demand)
+  bool is_rect = false;
+  int x0 = 0, y0 = 0, x1 = -1, y1 = -1; // inclusive rectangle (is_rect)
   float cx = 0.f, cy = 0.f;
   bool set = false;
+  int n0() const { return is_rect ? (x1 - x0 + 1) * (y1 - y0 + 1) : (int)(xy.size() / 2); }
+  std::vector<float> points() const { // level-0 list in the CPU engine's order
+    if (!is_rect)
+      return xy;
+    std::vector<float> v;
+    v.reserve(2 * (size_t)n0());
+    lkroi::rect_points(x0, y0, x1, y1, v);
+    return v;
+  }
 };
+
+// floor(a / 2^l) and ceil(a / 2^l) for any sign
+static int floor_shift(int a, int l) { return a >> l; }
+static int ceil_shift(int a, int l) { return -((-a) >> l); }
 
 template <class T> struct DevBuf {
   T *p = nullptr;
@@ -108,6 +123,8 @@ struct lk_engine {
   std::vector<uint32_t> h_off[LK_MAX_LEVELS];
   DevBuf<float2> d_xy[LK_MAX_LEVELS];
   DevBuf<uint32_t> d_off[LK_MAX_LEVELS];
+  DevBuf<int4> d_rect[LK_MAX_LEVELS];
+  std::vector<int4> h_rect[LK_MAX_LEVELS];
   std::vector<float> h_center; // [S][2]
   DevBuf<float2> d_center;
   DevBuf<float> d_guess, d_last_p, d_prev_p;
@@ -194,6 +211,7 @@ void lk_destroy(lk_engine *e) {
   for (int l = 0; l < LK_MAX_LEVELS; ++l) {
     e->d_xy[l].release();
     e->d_off[l].release();
+    e->d_rect[l].release();
   }
   e->d_center.release();
   e->d_guess.release();
@@ -389,8 +407,11 @@ int lk_set_sector_rect(lk_engine *e, int sector, int x0, int y0, int x1, int y1)
   if (!s || x1 < x0 || y1 < y0)
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sector_rect: bad rectangle");
   s->xy.clear();
-  s->xy.reserve(2 * (size_t)(x1 - x0 + 1) * (size_t)(y1 - y0 + 1));
-  lkroi::rect_points(x0, y0, x1, y1, s->xy);
+  s->is_rect = true;
+  s->x0 = x0;
+  s->y0 = y0;
+  s->x1 = x1;
+  s->y1 = y1;
   s->cx = (float)(x0 + x1) * 0.5f;
   s->cy = (float)(y0 + y1) * 0.5f;
   s->set = true;
@@ -418,8 +439,11 @@ int lk_set_rect_grid(lk_engine *e, float x_begin, float y_begin, float x_end, fl
     int iSector = first + k, i = iSector / vs, j = iSector % vs; // iSector = i*vs + j
     HostSector &s = e->hs[(size_t)k];
     int cx = g.cx[i], cy = g.cy[j];
-    s.xy.reserve(2 * (size_t)(2 * g.xdim + 1) * (size_t)(2 * g.ydim + 1));
-    lkroi::rect_points(cx - g.xdim, cy - g.ydim, cx + g.xdim, cy + g.ydim, s.xy);
+    s.is_rect = true;
+    s.x0 = cx - g.xdim;
+    s.y0 = cy - g.ydim;
+    s.x1 = cx + g.xdim;
+    s.y1 = cy + g.ydim;
     s.cx = (float)cx; // manager_class.cpp:438-441 passes the integer centre
     s.cy = (float)cy;
     s.set = true;
@@ -435,6 +459,7 @@ int lk_set_sector_annular(lk_engine *e, int sector, float r, float dr, float a, 
   if (!s)
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sector_annular: bad sector index");
   s->xy.clear();
+  s->is_rect = false;
   if (!lkroi::annular_points(r, dr, a, da, cx, cy, as, s->xy) || s->xy.empty())
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sector_annular: empty sector");
   lkroi::mean_center(s->xy.data(), (int)(s->xy.size() / 2), s->cx, s->cy); // correlation_class.cpp:337-339
@@ -449,6 +474,7 @@ int lk_set_sector_blob(lk_engine *e, int sector, const float *contour_xy, int n_
   if (!s || !contour_xy)
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sector_blob: bad arguments");
   s->xy.clear();
+  s->is_rect = false;
   if (!lkroi::BlobPolygon::inside_points(contour_xy, n_vertices, s->xy) || s->xy.empty()) {
     s->set = false;
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sector_blob: contour is not a simple polygon");
@@ -466,6 +492,7 @@ int lk_set_sector_points(lk_engine *e, int sector, const float *xy, int n, int u
   if (!s || !xy || n < 1)
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sector_points: bad arguments");
   s->xy.assign(xy, xy + 2 * (size_t)n);
+  s->is_rect = false;
   if (use_center) {
     s->cx = cx;
     s->cy = cy;
@@ -503,11 +530,25 @@ int lk_commit_sectors(lk_engine *e) {
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_commit_sectors: more than 2^32 samples");
   cat[0].reserve(total0);
   e->h_center.resize(2 * (size_t)S);
+  for (int l : levels)
+    e->h_rect[l].assign((size_t)S, make_int4(0, 0, 0, 0));
   std::vector<float> prev, cur;
   for (int s = 0; s < S; ++s) {
     const HostSector &hs = e->hs[(size_t)s];
     e->h_center[2 * (size_t)s] = hs.cx;
     e->h_center[2 * (size_t)s + 1] = hs.cy;
+    if (hs.is_rect) {
+      // the decimation rule of pyramid_class.cpp:301-322 applied to a full rectangle keeps
+      // exactly the coordinates divisible by 2^l, i.e. another full rectangle, same order
+      for (int l : levels) {
+        int xs = ceil_shift(hs.x0, l), xe = floor_shift(hs.x1, l);
+        int ys = ceil_shift(hs.y0, l), ye = floor_shift(hs.y1, l);
+        int w = std::max(0, xe - xs + 1), h = std::max(0, ye - ys + 1);
+        e->h_rect[l][(size_t)s] = make_int4(xs, ys, std::max(w, 1), w * h);
+        e->h_off[l].push_back((uint32_t)(cat[l].size() / 2));
+      }
+      continue;
+    }
     cat[0].insert(cat[0].end(), hs.xy.begin(), hs.xy.end());
     e->h_off[0].push_back((uint32_t)(cat[0].size() / 2));
     const float *pxy = hs.xy.data();
@@ -531,6 +572,8 @@ int lk_commit_sectors(lk_engine *e) {
       HIPCHK(hipMemcpy(e->d_xy[l].p, cat[l].data(), cat[l].size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_off[l].p, e->h_off[l].data(), ((size_t)S + 1) * sizeof(uint32_t),
                      hipMemcpyHostToDevice));
+    HIPCHK(e->d_rect[l].ensure((size_t)S));
+    HIPCHK(hipMemcpy(e->d_rect[l].p, e->h_rect[l].data(), (size_t)S * sizeof(int4), hipMemcpyHostToDevice));
   }
   HIPCHK(e->d_center.ensure((size_t)S));
   HIPCHK(hipMemcpy(e->d_center.p, e->h_center.data(), 2 * (size_t)S * sizeof(float), hipMemcpyHostToDevice));
@@ -548,7 +591,7 @@ int lk_commit_sectors(lk_engine *e) {
   e->h_class.assign((size_t)S, 0);
   size_t cnt[kNumClasses] = {0, 0, 0, 0}, tot[kNumClasses] = {0, 0, 0, 0};
   for (int s = 0; s < S; ++s) {
-    int n0 = (int)(e->hs[(size_t)s].xy.size() / 2), c = size_class(n0);
+    int n0 = e->hs[(size_t)s].n0(), c = size_class(n0);
     e->h_class[(size_t)s] = c;
     cnt[c]++;
     tot[c] += (size_t)n0;
@@ -596,7 +639,7 @@ int lk_get_sector_info(lk_engine *e, int sector, int *n_points, float *cx, float
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_sector_info: unknown sector");
   const HostSector &s = e->hs[(size_t)sector];
   if (n_points)
-    *n_points = (int)(s.xy.size() / 2);
+    *n_points = s.n0();
   if (cx)
     *cx = s.cx;
   if (cy)
@@ -610,8 +653,10 @@ int lk_get_sector_level_count(lk_engine *e, int sector, int level, int *n) {
   if (!e->committed || sector < 0 || sector >= e->S || level < 0 || level >= LK_MAX_LEVELS ||
       e->h_off[level].size() != (size_t)e->S + 1)
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_sector_level_count: unknown sector/level");
-  if (n)
-    *n = (int)(e->h_off[level][(size_t)sector + 1] - e->h_off[level][(size_t)sector]);
+  if (n) {
+    const int4 r = e->h_rect[level][(size_t)sector];
+    *n = r.z > 0 ? r.w : (int)(e->h_off[level][(size_t)sector + 1] - e->h_off[level][(size_t)sector]);
+  }
   return LK_ERROR_NONE;
 }
 
@@ -621,11 +666,13 @@ int lk_get_und_xy(lk_engine *e, int sector, float *xy, int cap, int *count) {
   if (sector < 0 || (size_t)sector >= e->hs.size() || !e->hs[(size_t)sector].set)
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_und_xy: unknown sector");
   const HostSector &s = e->hs[(size_t)sector];
-  int n = (int)(s.xy.size() / 2);
+  int n = s.n0();
   if (count)
     *count = n;
-  if (xy && cap > 0)
-    std::memcpy(xy, s.xy.data(), 2 * sizeof(float) * (size_t)std::min(n, cap));
+  if (xy && cap > 0) {
+    std::vector<float> pts = s.points();
+    std::memcpy(xy, pts.data(), 2 * sizeof(float) * (size_t)std::min(n, cap));
+  }
   return LK_ERROR_NONE;
 }
 
@@ -634,19 +681,21 @@ int lk_get_def_xy(lk_engine *e, int sector, const float *p, float *xy, int cap, 
     return LK_ERROR_BAD_DOMAIN;
   if (!e->committed || sector < 0 || sector >= e->S || !p)
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_def_xy: unknown sector");
-  const uint32_t off = e->h_off[0][(size_t)sector];
-  const int n = (int)(e->h_off[0][(size_t)sector + 1] - off);
+  const std::vector<float> pts = e->hs[(size_t)sector].points();
+  const int n = (int)(pts.size() / 2);
   if (count)
     *count = n;
   if (!xy || cap <= 0)
     return LK_ERROR_NONE;
   HIPCHK(hipSetDevice(e->cfg.device));
-  HIPCHK(e->d_warp.ensure((size_t)n));
+  HIPCHK(e->d_warp.ensure(2 * (size_t)n));
+  HIPCHK(hipMemcpyAsync(e->d_warp.p + n, pts.data(), 2 * sizeof(float) * (size_t)n, hipMemcpyHostToDevice,
+                        e->stream));
   float pp[6] = {0, 0, 0, 0, 0, 0};
   for (int i = 0; i < e->P; ++i)
     pp[i] = p[i];
   HIPCHK(hipMemcpyAsync(e->d_scratch.p, pp, sizeof(pp), hipMemcpyHostToDevice, e->stream));
-  HIPCHK(lk_launch_warp_points(e->d_xy[0].p + off, n, e->h_center[2 * (size_t)sector],
+  HIPCHK(lk_launch_warp_points(e->d_warp.p + n, n, e->h_center[2 * (size_t)sector],
                                e->h_center[2 * (size_t)sector + 1], e->cfg.fitting_model, e->d_scratch.p,
                                e->d_warp.p, e->stream));
   HIPCHK(hipMemcpyAsync(xy, e->d_warp.p, 2 * sizeof(float) * (size_t)std::min(n, cap),
@@ -676,6 +725,7 @@ static int refresh_level_views(lk_engine *e) {
     v.def = d.lvl[l];
     v.xy = e->d_xy[l].p;
     v.off = e->d_off[l].p;
+    v.rect = e->d_rect[l].p;
     v.urows = u.rows >> l;
     v.ucols = u.cols >> l;
     v.drows = d.rows >> l;

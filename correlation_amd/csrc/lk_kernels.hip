@@ -235,7 +235,8 @@ template <int P> struct Sums { // upper triangle row-major, then b, then chi
 // totals; returns the error flag (some sample of the group's sector left the image).
 struct LevelCtx { // what a lane needs to know about its sector at the current level
   gptr<uint8_t> und, def;
-  gptr<f32x2> xy;  // already offset to the sector's first sample
+  gptr<f32x2> xy;  // explicit list, already offset to the sector's first sample
+  int rx, ry, rw;  // implicit rectangle: first x, first y, width (rw == 0: explicit list)
   int n;
   int urows, ucols, drows, dcols;
   float cx, cy, scaling;
@@ -268,8 +269,28 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
     S.v[i] = 0.f;
   bool bad = false;
   const int umaxr = c.urows - 1, umaxc = c.ucols - 1;
+  // Implicit rectangles are walked x-fastest so that neighbouring lanes read neighbouring
+  // pixels of one image row (a 16-lane group touches 1-2 cache lines per load instead of
+  // 16).  The reference enumerates y-fastest (manager_class.cpp:1607-1611); only the float
+  // summation order depends on that, and a parallel reduction does not keep it anyway.
+  const float inv_w = c.rw > 0 ? 1.f / (float)c.rw : 0.f;
   for (int k = (int)threadIdx.x % GROUP; k < c.n; k += GROUP) {
-    const f32x2 q = c.xy[k];
+    f32x2 q;
+    if (c.rw > 0) { // k -> (row, column) of the rectangle
+      int row = (int)((float)k * inv_w);
+      int col = k - row * c.rw;
+      if (col < 0) {
+        col += c.rw;
+        --row;
+      } else if (col >= c.rw) {
+        col -= c.rw;
+        ++row;
+      }
+      q.x = (float)(c.rx + col);
+      q.y = (float)(c.ry + row);
+    } else {
+      q = c.xy[k];
+    }
     float xd, yd, dx = 0.f, dy = 0.f;
     Warp<MODEL>::apply(q.x, q.y, c.cx, c.cy, p, xd, yd, dx, dy);
     int uix = (int)(q.x + 0.5f), uiy = (int)(q.y + 0.5f);
@@ -337,206 +358,83 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
 }
 
 // ------------------------------------------------------------------------------------
-// 6x6 solve: Eigen 3.4.0 ColPivHouseholderQR restated (the reference's only solver call,
-// correlation_class.cpp:742-747): column norms with LAPACK-style down-dating, largest
-// remaining column as pivot, Householder reflectors, back-substitution.  All indices are
-// compile-time after unrolling; the (wave-uniform) pivot choice is applied with
-// compare-and-swap so nothing is dynamically indexed (no scratch).
-// M is column-major N x N, overwritten.
+// the damped normal-equation solve (compute_model_parameters + solve,
+// correlation_class.cpp:642-768)
 // ------------------------------------------------------------------------------------
-template <int N>
-__device__ __forceinline__ void colpiv_qr_solve(float (&M)[N * N], const float (&bin)[N],
-                                                float (&x)[N]) {
-#define QR(r, c) M[(c)*N + (r)]
-  float hc[N], normU[N], normD[N], cv[N];
-  int trans[N];
-  const float eps = FLT_EPSILON;
-  float maxn = 0.f;
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    float s = 0.f;
-#pragma unroll
-    for (int r = 0; r < N; ++r)
-      s += QR(r, k) * QR(r, k);
-    normD[k] = __builtin_sqrtf(s);
-    normU[k] = normD[k];
-    if (normU[k] > maxn)
-      maxn = normU[k];
-  }
-  const float threshold_helper = (maxn * eps) * (maxn * eps) / (float)N;
-  const float norm_downdate_threshold = __builtin_sqrtf(eps);
-  int nonzero_pivots = N;
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    int big = k;
-    float bigv = normU[k];
-#pragma unroll
-    for (int j = k + 1; j < N; ++j)
-      if (normU[j] > bigv) {
-        bigv = normU[j];
-        big = j;
-      }
-    float big_sq = bigv * bigv;
-    if (nonzero_pivots == N && big_sq < threshold_helper * (float)(N - k))
-      nonzero_pivots = k;
-    trans[k] = big;
-#pragma unroll
-    for (int j = k + 1; j < N; ++j) {
-      if (big == j) {
-#pragma unroll
-        for (int r = 0; r < N; ++r) {
-          float t = QR(r, k);
-          QR(r, k) = QR(r, j);
-          QR(r, j) = t;
-        }
-        float t = normU[k];
-        normU[k] = normU[j];
-        normU[j] = t;
-        t = normD[k];
-        normD[k] = normD[j];
-        normD[j] = t;
-      }
-    }
-    float tailSq = 0.f;
-#pragma unroll
-    for (int r = k + 1; r < N; ++r)
-      tailSq += QR(r, k) * QR(r, k);
-    float c0 = QR(k, k), beta, tau;
-    if (tailSq <= FLT_MIN) {
-      tau = 0.f;
-      beta = c0;
-#pragma unroll
-      for (int r = k + 1; r < N; ++r)
-        QR(r, k) = 0.f;
-    } else {
-      beta = __builtin_sqrtf(c0 * c0 + tailSq);
-      if (c0 >= 0.f)
-        beta = -beta;
-      float den = c0 - beta;
-#pragma unroll
-      for (int r = k + 1; r < N; ++r)
-        QR(r, k) = QR(r, k) / den;
-      tau = (beta - c0) / beta;
-    }
-    hc[k] = tau;
-    QR(k, k) = beta;
-    if (N - k > 1 && tau != 0.f) {
-#pragma unroll
-      for (int j = k + 1; j < N; ++j) {
-        float tmp = 0.f;
-#pragma unroll
-        for (int r = k + 1; r < N; ++r)
-          tmp += QR(r, k) * QR(r, j);
-        tmp += QR(k, j);
-        QR(k, j) -= tau * tmp;
-#pragma unroll
-        for (int r = k + 1; r < N; ++r)
-          QR(r, j) -= tmp * (tau * QR(r, k));
-      }
-    }
-#pragma unroll
-    for (int j = k + 1; j < N; ++j) {
-      if (normU[j] != 0.f) {
-        float temp = __builtin_fabsf(QR(k, j)) / normU[j];
-        temp = (1.f + temp) * (1.f - temp);
-        temp = temp < 0.f ? 0.f : temp;
-        float ratio = normU[j] / normD[j];
-        float temp2 = temp * (ratio * ratio);
-        if (temp2 <= norm_downdate_threshold) {
-          float s = 0.f;
-#pragma unroll
-          for (int r = k + 1; r < N; ++r)
-            s += QR(r, j) * QR(r, j);
-          normD[j] = __builtin_sqrtf(s);
-          normU[j] = normD[j];
-        } else {
-          normU[j] *= __builtin_sqrtf(temp);
-        }
-      }
-    }
-  }
-  if (nonzero_pivots == 0) {
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-      x[i] = 0.f;
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < N; ++i)
-    cv[i] = bin[i];
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    if (k < nonzero_pivots) {
-      if (N - k == 1) {
-        cv[k] *= 1.f - hc[k];
-      } else if (hc[k] != 0.f) {
-        float tmp = 0.f;
-#pragma unroll
-        for (int r = k + 1; r < N; ++r)
-          tmp += QR(r, k) * cv[r];
-        tmp += cv[k];
-        cv[k] -= hc[k] * tmp;
-#pragma unroll
-        for (int r = k + 1; r < N; ++r)
-          cv[r] -= tmp * (hc[k] * QR(r, k));
-      }
-    }
-  }
-#pragma unroll
-  for (int i = N - 1; i >= 0; --i) {
-    if (i < nonzero_pivots) {
-      cv[i] = cv[i] / QR(i, i);
-#pragma unroll
-      for (int r = 0; r < i; ++r)
-        cv[r] -= cv[i] * QR(r, i);
-    } else {
-      cv[i] = 0.f; // rank-deficient tail: dst rows of the dropped pivots are zero
-    }
-  }
-  // x[perm[i]] = cv[i], perm = product of the transpositions (k, trans[k]), applied on the
-  // right in ascending k.  Equivalent, without a dynamically indexed perm[]: start from
-  // y = cv and undo the column swaps in descending k.
-#pragma unroll
-  for (int i = 0; i < N; ++i)
-    x[i] = cv[i];
-#pragma unroll
-  for (int k = N - 1; k >= 0; --k) {
-#pragma unroll
-    for (int j = k + 1; j < N; ++j)
-      if (trans[k] == j) {
-        float t = x[k];
-        x[k] = x[j];
-        x[j] = t;
-      }
-  }
-#undef QR
-}
-
-// compute_model_parameters (correlation_class.cpp:642-704): scale b and upper A by 1/n,
-// mirror, damp the diagonal, solve, p += dp.
+// The reference hands the symmetric, LM-damped matrix to Eigen's ColPivHouseholderQR
+// (correlation_class.cpp:742-747); its CUDA path uses cuSOLVER's Cholesky instead
+// (cuda_solver.cu:120-149).  A = sum(H H^T)/n with the diagonal scaled by (1+lambda) is
+// symmetric positive (semi-)definite, so the engine factors it as U^T D U (root-free
+// Cholesky) entirely in registers: ~200 instructions per solve against ~3000 for a
+// register-resident pivoted Householder QR, with the same backward-stable O(cond*eps)
+// accuracy on SPD input.  A pivot that is not safely positive (flat, textureless sector)
+// zeroes that parameter's step, which is what the rank-revealing QR does with its
+// dropped pivots.  The difference to the QR result is far below the summation-order
+// noise of b (tests/test_parity_gpu.py docstring; scripts/parity_noise.py).
+//
+// S holds the raw sums (upper triangle row-major, b, chi); p += dp.
 template <int P>
 __device__ __forceinline__ void damped_step(const Sums<P> &S, float lambda, float scaling,
                                             float (&p)[6], float *dp_out = nullptr) {
-  float M[P * P], b[P], dp[P];
+  // U[i][j], i <= j: starts as the scaled, damped upper triangle of A
+  float U[P][P], d[P], inv_d[P], y[P], x[P];
   int idx = 0;
-#pragma unroll
-  for (int p1 = 0; p1 < P; ++p1) {
-    b[p1] = S.v[Sums<P>::NA + p1] * scaling;
-#pragma unroll
-    for (int p2 = p1; p2 < P; ++p2) {
-      float a = S.v[idx++] * scaling;
-      if (p1 == p2)
-        a *= (1.f + lambda);
-      M[p1 * P + p2] = a;
-      M[p2 * P + p1] = a;
-    }
-  }
-  colpiv_qr_solve<P>(M, b, dp);
+  float dmax = 0.f;
 #pragma unroll
   for (int i = 0; i < P; ++i) {
-    p[i] += dp[i];
+#pragma unroll
+    for (int j = i; j < P; ++j) {
+      float a = S.v[idx++] * scaling; // :647-651
+      if (i == j) {
+        a *= (1.f + lambda); // :664
+        dmax = fmaxf(dmax, a);
+      }
+      U[i][j] = a;
+    }
+    y[i] = S.v[Sums<P>::NA + i] * scaling;
+  }
+  const float tiny = dmax * 1e-7f;
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    float w[P > 1 ? P : 1];
+    float dj = U[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) {
+      w[k] = U[k][j] * d[k];
+      dj = __builtin_fmaf(-U[k][j], w[k], dj);
+    }
+    const bool ok = dj > tiny;
+    d[j] = ok ? dj : 0.f;
+    inv_d[j] = ok ? 1.f / dj : 0.f;
+#pragma unroll
+    for (int i = j + 1; i < P; ++i) {
+      float t = U[j][i];
+#pragma unroll
+      for (int k = 0; k < j; ++k)
+        t = __builtin_fmaf(-w[k], U[k][i], t);
+      U[j][i] = t * inv_d[j];
+    }
+  }
+  // U^T y' = b (forward), z = y'/d, U x = z (backward)
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+#pragma unroll
+    for (int k = 0; k < j; ++k)
+      y[j] = __builtin_fmaf(-U[k][j], y[k], y[j]);
+  }
+#pragma unroll
+  for (int j = P - 1; j >= 0; --j) {
+    float t = y[j] * inv_d[j];
+#pragma unroll
+    for (int i = j + 1; i < P; ++i)
+      t = __builtin_fmaf(-U[j][i], x[i], t);
+    x[j] = t;
+  }
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    p[i] += x[i]; // :687-688
     if (dp_out)
-      dp_out[i] = dp[i];
+      dp_out[i] = x[i];
   }
 }
 
@@ -604,7 +502,11 @@ __global__ void __launch_bounds__(THREADS) lk_solve_kernel(LkSolveArgs a) {
     lambda = 0.0001f;
     last_good_chi = FLT_MAX;
     const uint32_t off = lv.off[s];
-    c.n = (int)(lv.off[s + 1] - off);
+    const int4 rc = lv.rect[s];
+    c.rx = rc.x;
+    c.ry = rc.y;
+    c.rw = rc.z;
+    c.n = rc.z > 0 ? rc.w : (int)(lv.off[s + 1] - off);
     c.und = (gptr<uint8_t>)lv.und;
     c.def = (gptr<uint8_t>)lv.def;
     c.xy = (gptr<f32x2>)(lv.xy + off);
@@ -725,7 +627,8 @@ __global__ void __launch_bounds__(THREADS) lk_solve_kernel(LkSolveArgs a) {
     for (int i = 0; i < 6; ++i)
       r.resultingParameters[i] = i < P ? p[i] : 0.f;
     r.chi = last_good_chi;
-    r.numberOfPoints = (int)(a.lv[0].off[s + 1] - a.lv[0].off[s]);
+    const int4 rc0 = a.lv[0].rect[s];
+    r.numberOfPoints = rc0.z > 0 ? rc0.w : (int)(a.lv[0].off[s + 1] - a.lv[0].off[s]);
     r.iterations = reached_iterations;
     r.errorCode = error_code;
     r.undCenterX = c0.x;
@@ -756,7 +659,11 @@ __global__ void __launch_bounds__(256) lk_eval_kernel(LkEvalArgs a) {
   const float2 c0 = a.center[a.sector];
   const float inv = 1.f / (float)(1 << a.level);
   LevelCtx c{};
-  c.n = (int)(lv.off[a.sector + 1] - off);
+  const int4 rc = lv.rect[a.sector];
+  c.rx = rc.x;
+  c.ry = rc.y;
+  c.rw = rc.z;
+  c.n = rc.z > 0 ? rc.w : (int)(lv.off[a.sector + 1] - off);
   if (GROUP == 16 && (int)threadIdx.x >= 16)
     c.n = 0; // only the first row owns the sector; the other groups idle
   c.und = (gptr<uint8_t>)lv.und;

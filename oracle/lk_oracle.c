@@ -619,6 +619,79 @@ void lko_colpiv_qr_solve(int n, const float *Ain, const float *bin, float *x) {
 #undef QR
 }
 
+/* lko_config.solver: 0 = the reference's solver (default), 1 = float32 root-free Cholesky,
+ * 2 = float64 Gaussian elimination.  1 and 2 are yardsticks: they measure how much of the
+ * engine-vs-reference deviation is explained by using a different backward-stable solver. */
+static _Thread_local int g_solver = 0;
+
+static void solve_ldlt_f32(int n, const float *A, const float *b, float *x) {
+  float U[6][6], d[6], inv[6], y[6], dmax = 0.f;
+  for (int i = 0; i < n; ++i) {
+    for (int j = i; j < n; ++j)
+      U[i][j] = A[i * n + j];
+    if (U[i][i] > dmax)
+      dmax = U[i][i];
+    y[i] = b[i];
+  }
+  float tiny = dmax * 1e-7f;
+  for (int j = 0; j < n; ++j) {
+    float w[6], dj = U[j][j];
+    for (int k = 0; k < j; ++k) {
+      w[k] = U[k][j] * d[k];
+      dj = fmaf(-U[k][j], w[k], dj);
+    }
+    int ok = dj > tiny;
+    d[j] = ok ? dj : 0.f;
+    inv[j] = ok ? 1.f / dj : 0.f;
+    for (int i = j + 1; i < n; ++i) {
+      float t = U[j][i];
+      for (int k = 0; k < j; ++k)
+        t = fmaf(-w[k], U[k][i], t);
+      U[j][i] = t * inv[j];
+    }
+  }
+  for (int j = 0; j < n; ++j)
+    for (int k = 0; k < j; ++k)
+      y[j] = fmaf(-U[k][j], y[k], y[j]);
+  for (int j = n - 1; j >= 0; --j) {
+    float t = y[j] * inv[j];
+    for (int i = j + 1; i < n; ++i)
+      t = fmaf(-U[j][i], x[i], t);
+    x[j] = t;
+  }
+}
+
+static void solve_f64(int n, const float *A, const float *b, float *x) {
+  double M[6][7];
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < n; ++j)
+      M[i][j] = A[i * n + j];
+    M[i][n] = b[i];
+  }
+  for (int c = 0; c < n; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < n; ++r)
+      if (fabs(M[r][c]) > fabs(M[piv][c]))
+        piv = r;
+    for (int j = 0; j <= n; ++j) {
+      double t = M[c][j];
+      M[c][j] = M[piv][j];
+      M[piv][j] = t;
+    }
+    for (int r = c + 1; r < n; ++r) {
+      double f = M[r][c] / M[c][c];
+      for (int j = c; j <= n; ++j)
+        M[r][j] -= f * M[c][j];
+    }
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double t = M[i][n];
+    for (int j = i + 1; j < n; ++j)
+      t -= M[i][j] * x[j];
+    x[i] = (float)(t / M[i][i]);
+  }
+}
+
 /* correlation_class.cpp:642-704 (scale, mirror, damp) + :719-768 (solve) */
 void lko_damped_solve(int n, float *A, float *b, float lambda, float scaling, float *dp) {
   for (int p1 = 0; p1 < n; ++p1) {
@@ -631,7 +704,12 @@ void lko_damped_solve(int n, float *A, float *b, float lambda, float scaling, fl
       A[p1 * n + p2] = A[p2 * n + p1];
     A[p1 * n + p1] *= (1.f + lambda);
   }
-  lko_colpiv_qr_solve(n, A, b, dp); /* symmetric: row-major == column-major view */
+  if (g_solver == 1)
+    solve_ldlt_f32(n, A, b, dp);
+  else if (g_solver == 2)
+    solve_f64(n, A, b, dp);
+  else
+    lko_colpiv_qr_solve(n, A, b, dp); /* symmetric: row-major == column-major view */
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -703,6 +781,7 @@ int lko_newton_raphson(lko_engine *e, float *p, int n0, const float *xy, int use
   const lko_image *und = &e->img[LKO_IMG_UND], *def = &e->img[LKO_IMG_DEF];
   int tcount = 0;
   g_eval_threads = cfg->n_threads;
+  g_solver = cfg->solver;
   if (n_trace)
     *n_trace = 0;
   if (und->n_levels == 0 || def->n_levels == 0 || n0 < 0)

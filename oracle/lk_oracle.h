@@ -54,6 +54,11 @@ typedef struct {
                        summed from zero, chunk totals added in thread order.  0/1 = one
                        chunk.  (The reference really spawns threads; the arithmetic is the
                        same, only this split matters for the bits.) */
+  int solver;       /* 0: the reference's solver, Eigen ColPivHouseholderQR restated (default).
+                       Yardsticks only (never the parity target): 1 = float32 root-free
+                       Cholesky, 2 = float64 Gaussian elimination ("exact" solve of the same
+                       float32 system).  They measure how far ANY other backward-stable
+                       solver lands from the QR's float32 rounding. */
   int cache_mode;   /* 0: coefficients computed per use (values identical to the
                        reference's lazy cache as long as no out-of-image error has
                        occurred on this def image); 1: emulate the lazy per-pixel

@@ -22,7 +22,7 @@ N_PARAMS = {0: 1, 1: 2, 2: 3, 3: 6}
 class Config(C.Structure):
     _fields_ = [("interp", C.c_int), ("model", C.c_int), ("precision", C.c_float),
                 ("max_iters", C.c_int), ("py_start", C.c_int), ("py_step", C.c_int),
-                ("py_stop", C.c_int), ("n_threads", C.c_int), ("cache_mode", C.c_int)]
+                ("py_stop", C.c_int), ("n_threads", C.c_int), ("solver", C.c_int), ("cache_mode", C.c_int)]
 
 
 RESULT_DTYPE = np.dtype([("p", np.float32, (6,)), ("chi", np.float32), ("n_points", np.int32),
@@ -92,10 +92,10 @@ class Oracle:
     """The reference's CorrelationClass, restated (see lk_oracle.h)."""
 
     def __init__(self, interp=IM_BICUBIC, model=FM_UVUXUYVXVY, precision=1e-3, max_iters=50,
-                 py_start=0, py_step=1, py_stop=2, cache_mode=0, n_threads=1):
+                 py_start=0, py_step=1, py_stop=2, cache_mode=0, n_threads=1, solver=0):
         self.L = lib()
         self.cfg = Config(interp, model, precision, max_iters, py_start, py_step, py_stop, n_threads,
-                          cache_mode)
+                          solver, cache_mode)
         self.n_params = N_PARAMS[model]
         self.h = self.L.lko_create(C.byref(self.cfg))
         if not self.h:
