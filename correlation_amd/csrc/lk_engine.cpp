@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -99,9 +100,11 @@ template <class T> struct DevBuf {
 
 // lanes that own one sector: a 16-lane DPP row (4 sectors per wavefront), one wavefront,
 // or a workgroup of 4 / 8 wavefronts
-static const int kNumClasses = 4;
-static const int kGroupOfClass[kNumClasses] = {16, 64, 256, 512};
-static int size_class(int n0) { return n0 <= 1024 ? 0 : (n0 <= 8192 ? 1 : (n0 <= 65536 ? 2 : 3)); }
+static const int kNumClasses = 5;
+static const int kGroupOfClass[kNumClasses] = {16, 32, 64, 256, 512};
+static int size_class(int n0) {
+  return n0 <= 512 ? 0 : (n0 <= 2048 ? 1 : (n0 <= 8192 ? 2 : (n0 <= 65536 ? 3 : 4)));
+}
 
 struct lk_engine {
   lk_config cfg{};
@@ -132,7 +135,7 @@ struct lk_engine {
   DevBuf<uint32_t> d_stats;
   DevBuf<uint32_t> d_order;
   std::vector<uint32_t> h_order; // sectors grouped by size class
-  int class_begin[kNumClasses + 1] = {0, 0, 0, 0, 0};
+  int class_begin[kNumClasses + 1] = {0, 0, 0, 0, 0, 0};
   std::vector<int> h_class; // size class of every sector
   DevBuf<uint32_t> d_single;
   DevBuf<float> d_scratch; // 64 floats for the stand-alone entry points
@@ -589,7 +592,7 @@ int lk_commit_sectors(lk_engine *e) {
   // size classes -> lanes per sector.  A class whose sectors are too few to fill the chip
   // (< 2048 wavefronts) and still large per lane is promoted to the next wider group.
   e->h_class.assign((size_t)S, 0);
-  size_t cnt[kNumClasses] = {0, 0, 0, 0}, tot[kNumClasses] = {0, 0, 0, 0};
+  size_t cnt[kNumClasses] = {0, 0, 0, 0, 0}, tot[kNumClasses] = {0, 0, 0, 0, 0};
   for (int s = 0; s < S; ++s) {
     int n0 = e->hs[(size_t)s].n0(), c = size_class(n0);
     e->h_class[(size_t)s] = c;
@@ -599,9 +602,13 @@ int lk_commit_sectors(lk_engine *e) {
   for (int c = 0; c + 1 < kNumClasses; ++c) {
     if (!cnt[c])
       continue;
+    // Wavefronts are dealt to SIMD slots as earlier ones retire; that only balances the
+    // uneven per-sector iteration counts when there are a few times more wavefronts than
+    // slots (1024 SIMDs x ~3).  Otherwise use wider groups: fewer sectors per wavefront.
     size_t waves = cnt[c] * (size_t)kGroupOfClass[c] / 64;
     size_t per_lane = tot[c] / cnt[c] / (size_t)kGroupOfClass[c];
-    if (waves < 2048 && per_lane >= 32) {
+    const bool small_group = kGroupOfClass[c] < 64;
+    if ((small_group && waves < 4096 && per_lane >= 4) || (!small_group && waves < 2048 && per_lane >= 32)) {
       for (int s = 0; s < S; ++s)
         if (e->h_class[(size_t)s] == c)
           e->h_class[(size_t)s] = c + 1;
@@ -609,6 +616,12 @@ int lk_commit_sectors(lk_engine *e) {
       tot[c + 1] += tot[c];
       cnt[c] = tot[c] = 0;
     }
+  }
+  if (const char *f = std::getenv("LK_FORCE_GROUP")) { // tuning experiments only
+    int g = std::atoi(f);
+    for (int c = 0; c < kNumClasses; ++c)
+      if (kGroupOfClass[c] == g)
+        std::fill(e->h_class.begin(), e->h_class.end(), c);
   }
   e->h_order.clear();
   e->h_order.reserve((size_t)S);

@@ -81,10 +81,15 @@ __device__ __forceinline__ void cubic_1d(float p0, float p1, float p2, float p3,
 __device__ __forceinline__ void bicubic_coeffs(gptr<uint8_t> def, int cols, int ix, int iy,
                                                float (&a)[16]) {
   gptr<uint8_t> base = def + (size_t)(iy - 1) * (size_t)cols + (size_t)(ix - 1);
+#ifdef LK_EXP_NOLOAD
+  uint32_t r0 = (uint32_t)(ix * 2654435761u), r1 = r0 ^ (uint32_t)iy, r2 = r1 * 31u, r3 = r2 + 7u;
+  (void)base;
+#else
   uint32_t r0 = load_u32_unaligned(base);
   uint32_t r1 = load_u32_unaligned(base + cols);
   uint32_t r2 = load_u32_unaligned(base + 2 * (size_t)cols);
   uint32_t r3 = load_u32_unaligned(base + 3 * (size_t)cols);
+#endif
   // t[r][k]: x-direction transform of image row r
   float t0[4], t1[4], t2[4], t3[4];
   cubic_1d(ub0(r0), ub1(r0), ub2(r0), ub3(r0), t0[0], t0[1], t0[2], t0[3]);
@@ -274,6 +279,9 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
   // 16).  The reference enumerates y-fastest (manager_class.cpp:1607-1611); only the float
   // summation order depends on that, and a parallel reduction does not keep it anyway.
   const float inv_w = c.rw > 0 ? 1.f / (float)c.rw : 0.f;
+#ifdef LK_EXP_UNROLL
+#pragma unroll LK_EXP_UNROLL
+#endif
   for (int k = (int)threadIdx.x % GROUP; k < c.n; k += GROUP) {
     f32x2 q;
     if (c.rw > 0) { // k -> (row, column) of the rectangle
@@ -296,7 +304,11 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
     int uix = (int)(q.x + 0.5f), uiy = (int)(q.y + 0.5f);
     uix = min(max(uix, 0), umaxc); // memory safety only; valid sample lists never clamp
     uiy = min(max(uiy, 0), umaxr);
+#ifdef LK_EXP_NOLOAD
+    float und_w = (float)((uix * 7 + uiy * 13) & 255);
+#else
     float und_w = (float)c.und[(size_t)uiy * (size_t)c.ucols + (size_t)uix];
+#endif
     float W, Wx, Wy;
     if (!sample_def<INTERP>(c.def, c.drows, c.dcols, xd, yd, W, Wx, Wy)) {
       bad = true;
@@ -324,6 +336,12 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
   if constexpr (GROUP == 16) {
     const int row = ((int)threadIdx.x & 63) >> 4;
     return ((badmask >> (16 * row)) & 0xffffull) != 0ull;
+  } else if constexpr (GROUP == 32) { // two sectors per wavefront: add the partner row
+#pragma unroll
+    for (int i = 0; i < SumsT::N; ++i)
+      S.v[i] += __shfl_xor(S.v[i], 16, 64);
+    const int half = ((int)threadIdx.x & 63) >> 5;
+    return ((badmask >> (32 * half)) & 0xffffffffull) != 0ull;
   } else {
 #pragma unroll
     for (int i = 0; i < SumsT::N; ++i)
@@ -664,8 +682,8 @@ __global__ void __launch_bounds__(256) lk_eval_kernel(LkEvalArgs a) {
   c.ry = rc.y;
   c.rw = rc.z;
   c.n = rc.z > 0 ? rc.w : (int)(lv.off[a.sector + 1] - off);
-  if (GROUP == 16 && (int)threadIdx.x >= 16)
-    c.n = 0; // only the first row owns the sector; the other groups idle
+  if (GROUP < kWave && (int)threadIdx.x >= GROUP)
+    c.n = 0; // only the first group owns the sector; the others idle
   c.und = (gptr<uint8_t>)lv.und;
   c.def = (gptr<uint8_t>)lv.def;
   c.xy = (gptr<f32x2>)(lv.xy + off);
@@ -849,6 +867,7 @@ static hipError_t launch_solve_mi(const LkSolveArgs &a, int group, hipStream_t s
   dim3 grid((unsigned)(a.chunk * 8));
   switch (group) {
   case 16: hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, 16, 64>), grid, dim3(64), 0, st, a); break;
+  case 32: hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, 32, 64>), grid, dim3(64), 0, st, a); break;
   case 64: hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, 64, 64>), grid, dim3(64), 0, st, a); break;
   case 256: hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, 256, 256>), grid, dim3(256), 0, st, a); break;
   default: hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, 512, 512>), grid, dim3(512), 0, st, a); break;
@@ -890,6 +909,7 @@ template <int MODEL>
 static hipError_t launch_eval_m(const LkEvalArgs &a, int interp, int group, hipStream_t st) {
   switch (group) {
   case 16: return launch_eval_mg<MODEL, 16>(a, interp, st);
+  case 32: return launch_eval_mg<MODEL, 32>(a, interp, st);
   case 64: return launch_eval_mg<MODEL, 64>(a, interp, st);
   default: return launch_eval_mg<MODEL, 256>(a, interp, st);
   }
