@@ -137,7 +137,7 @@ struct lk_engine {
   std::vector<uint32_t> h_order; // sectors grouped by size class
   int class_begin[kNumClasses + 1] = {0, 0, 0, 0, 0, 0};
   std::vector<int> h_class; // size class of every sector
-  DevBuf<uint32_t> d_single;
+  DevBuf<uint32_t> d_single, d_queue;
   DevBuf<float> d_scratch; // 64 floats for the stand-alone entry points
   DevBuf<float2> d_warp;
   bool stats_valid = false;
@@ -224,6 +224,7 @@ void lk_destroy(lk_engine *e) {
   e->d_stats.release();
   e->d_order.release();
   e->d_single.release();
+  e->d_queue.release();
   e->d_scratch.release();
   e->d_warp.release();
   if (e->own_stream)
@@ -635,6 +636,7 @@ int lk_commit_sectors(lk_engine *e) {
   HIPCHK(e->d_order.ensure((size_t)S));
   HIPCHK(hipMemcpy(e->d_order.p, e->h_order.data(), (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice));
   HIPCHK(e->d_single.ensure(1));
+  HIPCHK(e->d_queue.ensure(kNumClasses));
   HIPCHK(e->d_scratch.ensure(64));
   e->S = S;
   e->committed = true;
@@ -767,13 +769,6 @@ static LkSolveArgs base_args(lk_engine *e, const float *d_guess, lk_result *d_re
   return a;
 }
 
-static void set_grid(LkSolveArgs &a, int n, int group) {
-  const int per_wg = group < 64 ? 64 / group : 1; // sectors per workgroup
-  const int n_wg = (n + per_wg - 1) / per_wg;
-  a.n_sectors = n;
-  a.chunk = (n_wg + 7) / 8;
-}
-
 static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
   HIPCHK(hipEventRecord(e->ev_s0, e->stream));
   for (int c = 0; c < kNumClasses; ++c) {
@@ -782,7 +777,8 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
       continue;
     LkSolveArgs a = base_args(e, d_guess, d_result);
     a.order = e->d_order.p + e->class_begin[c];
-    set_grid(a, n, kGroupOfClass[c]);
+    a.n_sectors = n;
+    a.queue = e->d_queue.p + c;
     HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, kGroupOfClass[c], e->stream));
   }
   HIPCHK(hipEventRecord(e->ev_s1, e->stream));
@@ -845,7 +841,8 @@ int lk_correlate(lk_engine *e, int sector, float *guess_inout, lk_result *out) {
   LkSolveArgs a = base_args(e, e->d_guess.p, e->d_result.p);
   a.order = e->d_single.p;
   const int group = kGroupOfClass[e->h_class[(size_t)sector]];
-  set_grid(a, 1, group);
+  a.n_sectors = 1;
+  a.queue = e->d_queue.p;
   HIPCHK(hipEventRecord(e->ev_s0, e->stream));
   HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, group, e->stream));
   HIPCHK(hipEventRecord(e->ev_s1, e->stream));

@@ -476,40 +476,33 @@ template <int P> __device__ __forceinline__ void translate(float (&p)[6], int sr
 //   TENT    evaluation of the tentative parameters + look-ahead solve (:503-529)
 //   REEVAL  reject path: re-evaluate at last_good with the larger lambda (:475-499)
 // GROUP == THREADS (64, 256, 512): one sector per workgroup, control flow is uniform.
-enum : int { PH_EVAL0 = 0, PH_TENT = 1, PH_REEVAL = 2, PH_DONE = 3 };
+// Work distribution: the launch is PERSISTENT.  Each lane group pulls the next sector from
+// a device-wide queue (one returning atomic per sector) when it has finished its current
+// one, so wavefronts stay full until the queue is empty whatever the per-sector iteration
+// counts are.  A group that finds the queue empty idles (n = 0) until its wavefront's other
+// groups are done; every wave reaches the exit test after each step, so the grid drains.
+enum : int { PH_EVAL0 = 0, PH_TENT = 1, PH_REEVAL = 2, PH_FETCH = 3, PH_EXIT = 4 };
 
 template <int MODEL, int INTERP, int GROUP, int THREADS>
 __global__ void __launch_bounds__(THREADS) lk_solve_kernel(LkSolveArgs a) {
   constexpr int P = n_params(MODEL);
   using SumsT = Sums<P>;
-  constexpr int SECTORS_PER_WG = THREADS / GROUP;
-  __shared__ float lds[GROUP > kWave ? (THREADS / kWave) * (SumsT::N + 1) : 1];
-
-  // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs, so give each
-  // XCD one contiguous run of sectors (neighbouring sectors share image rows in its L2).
-  const int b = (int)blockIdx.x;
-  const int wg_slot = (b & 7) * a.chunk + (b >> 3);
-  if (wg_slot * SECTORS_PER_WG >= a.n_sectors)
-    return;
-  const int slot = wg_slot * SECTORS_PER_WG + (int)threadIdx.x / GROUP;
-  const bool valid = slot < a.n_sectors;
-  const int s = valid ? (a.order ? (int)a.order[slot] : slot) : 0;
+  __shared__ float lds[GROUP > kWave ? (THREADS / kWave) * (SumsT::N + 1) + 1 : 1];
 
   float p[6], lg_p[6], tent[6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    p[i] = (i < P && valid) ? a.guess[(size_t)s * 6 + i] : 0.f;
-    lg_p[i] = tent[i] = 0.f;
-  }
-  const float2 c0 = a.center[s];
+  for (int i = 0; i < 6; ++i)
+    p[i] = lg_p[i] = tent[i] = 0.f;
   const float min_lambda = 1e-9f, max_lambda = 1e9f;
   float last_good_chi = FLT_MAX, lambda = 0.0001f;
   int reached_iterations = 0, iteration = 0;
   int error_code = LK_ERROR_NONE;
   uint32_t n_evals = 0, n_sample_evals = 0, n_point_iters = 0;
   int level = a.py_stop, level_old = 0;
+  int s = 0; // sector owned by this lane group
+  float2 c0 = make_float2(0.f, 0.f);
   bool use_saved = true;
-  int phase = valid ? PH_EVAL0 : PH_DONE;
+  int phase = PH_FETCH;
   LevelCtx c{};
   SumsT S;
 
@@ -541,17 +534,74 @@ __global__ void __launch_bounds__(THREADS) lk_solve_kernel(LkSolveArgs a) {
       lg_p[i] = p[i];
     phase = PH_EVAL0;
   };
-  if (valid)
-    enter_level();
+
+  auto finish_sector = [&]() { // results of Newton_Raphson (:638-639, :848-870)
+    if ((int)threadIdx.x % GROUP == 0) {
+      lk_result r;
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        r.resultingParameters[i] = i < P ? p[i] : 0.f;
+      r.chi = last_good_chi;
+      const int4 rc0 = a.lv[0].rect[s];
+      r.numberOfPoints = rc0.z > 0 ? rc0.w : (int)(a.lv[0].off[s + 1] - a.lv[0].off[s]);
+      r.iterations = reached_iterations;
+      r.errorCode = error_code;
+      r.undCenterX = c0.x;
+      r.undCenterY = c0.y;
+      a.result[s] = r;
+      if (a.last_p) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+          a.last_p[(size_t)s * 6 + i] = r.resultingParameters[i];
+      }
+      if (a.stats) {
+        a.stats[(size_t)s * 4 + 0] = n_evals;
+        a.stats[(size_t)s * 4 + 1] = n_sample_evals;
+        a.stats[(size_t)s * 4 + 2] = n_point_iters;
+        a.stats[(size_t)s * 4 + 3] = 0;
+      }
+    }
+    phase = PH_FETCH;
+  };
 
   for (;;) {
-    const bool active = phase != PH_DONE;
+    if (phase == PH_FETCH) { // pull the next sector
+      int slot = 0;
+      if constexpr (GROUP > kWave) {
+        __syncthreads(); // everybody is done reading lds from the last evaluation
+        if (threadIdx.x == 0)
+          reinterpret_cast<int *>(lds)[(THREADS / kWave) * (SumsT::N + 1)] = (int)atomicAdd(a.queue, 1u);
+        __syncthreads();
+        slot = reinterpret_cast<int *>(lds)[(THREADS / kWave) * (SumsT::N + 1)];
+      } else {
+        if ((int)threadIdx.x % GROUP == 0)
+          slot = (int)atomicAdd(a.queue, 1u);
+        slot = __shfl(slot, ((int)threadIdx.x & 63) & ~(GROUP - 1), 64);
+      }
+      if (slot < a.n_sectors) {
+        s = a.order ? (int)a.order[slot] : slot;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+          p[i] = i < P ? a.guess[(size_t)s * 6 + i] : 0.f;
+        c0 = a.center[s];
+        reached_iterations = 0;
+        iteration = 0;
+        n_evals = n_sample_evals = n_point_iters = 0;
+        level = a.py_stop;
+        level_old = 0;
+        use_saved = true;
+        enter_level();
+      } else {
+        phase = PH_EXIT;
+      }
+    }
+    const bool active = phase < PH_FETCH;
     if constexpr (GROUP >= kWave) {
       if (!active)
-        break; // uniform over the workgroup
+        break; // uniform over the workgroup: the queue is empty
     } else {
       if (__ballot(active) == 0ull)
-        break; // every sector of this wavefront is finished
+        break; // every group of this wavefront found the queue empty
     }
     LevelCtx ce = c;
     if (!active)
@@ -566,7 +616,7 @@ __global__ void __launch_bounds__(THREADS) lk_solve_kernel(LkSolveArgs a) {
         if (phase == PH_EVAL0) {
           ++n_point_iters;
           translate<P>(p, level, 0);
-          phase = PH_DONE;
+          finish_sector();
         } else {
           level_end = true;
         }
@@ -631,37 +681,11 @@ __global__ void __launch_bounds__(THREADS) lk_solve_kernel(LkSolveArgs a) {
         level -= a.py_step;
         if (level < a.py_start) {
           translate<P>(p, level_old, 0);
-          phase = PH_DONE;
+          finish_sector();
         } else {
           enter_level();
         }
       }
-    }
-  }
-
-  if ((int)threadIdx.x % GROUP == 0 && valid) {
-    lk_result r;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-      r.resultingParameters[i] = i < P ? p[i] : 0.f;
-    r.chi = last_good_chi;
-    const int4 rc0 = a.lv[0].rect[s];
-    r.numberOfPoints = rc0.z > 0 ? rc0.w : (int)(a.lv[0].off[s + 1] - a.lv[0].off[s]);
-    r.iterations = reached_iterations;
-    r.errorCode = error_code;
-    r.undCenterX = c0.x;
-    r.undCenterY = c0.y;
-    a.result[s] = r;
-    if (a.last_p) {
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-        a.last_p[(size_t)s * 6 + i] = r.resultingParameters[i];
-    }
-    if (a.stats) {
-      a.stats[(size_t)s * 4 + 0] = n_evals;
-      a.stats[(size_t)s * 4 + 1] = n_sample_evals;
-      a.stats[(size_t)s * 4 + 2] = n_point_iters;
-      a.stats[(size_t)s * 4 + 3] = 0;
     }
   }
 }
@@ -862,17 +886,38 @@ __global__ void lk_warp_points_kernel(const float2 *xy, int n, float cx, float c
 // ------------------------------------------------------------------------------------
 // launch wrappers (called from lk_engine.cpp)
 // ------------------------------------------------------------------------------------
+// Persistent launch: as many workgroups as the device keeps resident (or fewer when there
+// is less work).  Nothing waits on another workgroup, so an over-estimate is harmless.
+template <class K> static int resident_workgroups(K kernel, int threads) {
+  int dev = 0, cus = 256, per_cu = 1;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1)
+    per_cu = 1;
+  return cus * per_cu;
+}
+
+template <int MODEL, int INTERP, int GROUP, int THREADS>
+static hipError_t launch_solve_g(const LkSolveArgs &a, hipStream_t st) {
+  static int resident = 0; // per template instance (one device type per process)
+  if (resident == 0)
+    resident = resident_workgroups(lk_solve_kernel<MODEL, INTERP, GROUP, THREADS>, THREADS);
+  const int per_wg = THREADS / GROUP;
+  const int want = (a.n_sectors + per_wg - 1) / per_wg;
+  dim3 grid((unsigned)(want < resident ? want : resident));
+  hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, GROUP, THREADS>), grid, dim3(THREADS), 0, st, a);
+  return hipGetLastError();
+}
+
 template <int MODEL, int INTERP>
 static hipError_t launch_solve_mi(const LkSolveArgs &a, int group, hipStream_t st) {
-  dim3 grid((unsigned)(a.chunk * 8));
   switch (group) {
-  case 16: hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, 16, 64>), grid, dim3(64), 0, st, a); break;
-  case 32: hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, 32, 64>), grid, dim3(64), 0, st, a); break;
-  case 64: hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, 64, 64>), grid, dim3(64), 0, st, a); break;
-  case 256: hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, 256, 256>), grid, dim3(256), 0, st, a); break;
-  default: hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, 512, 512>), grid, dim3(512), 0, st, a); break;
+  case 16: return launch_solve_g<MODEL, INTERP, 16, 64>(a, st);
+  case 32: return launch_solve_g<MODEL, INTERP, 32, 64>(a, st);
+  case 64: return launch_solve_g<MODEL, INTERP, 64, 64>(a, st);
+  case 256: return launch_solve_g<MODEL, INTERP, 256, 256>(a, st);
+  default: return launch_solve_g<MODEL, INTERP, 512, 512>(a, st);
   }
-  return hipGetLastError();
 }
 
 template <int MODEL>
@@ -887,6 +932,9 @@ static hipError_t launch_solve_m(const LkSolveArgs &a, int interp, int group, hi
 hipError_t lk_launch_solve(const LkSolveArgs &a, int model, int interp, int group, hipStream_t st) {
   if (a.n_sectors <= 0)
     return hipSuccess;
+  hipError_t qe = hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st); // rewind the sector queue
+  if (qe != hipSuccess)
+    return qe;
   switch (model) {
   case LK_FM_U: return launch_solve_m<LK_FM_U>(a, interp, group, st);
   case LK_FM_UV: return launch_solve_m<LK_FM_UV>(a, interp, group, st);
