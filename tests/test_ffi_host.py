@@ -80,3 +80,20 @@ def test_speckle_generator_is_deterministic():
     a2, b2 = ca.speckle.speckle_pair(96, 128, seed=3)
     assert a1.dtype == np.uint8 and a1.shape == (96, 128)
     assert np.array_equal(a1, a2) and np.array_equal(b1, b2) and not np.array_equal(a1, b1)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference headers not present on this box")
+def test_cuda_class_adapter_compiles_against_reference_headers(tmp_path):
+    """include/lk_cuda_class_adapter.hpp is meant to be compiled inside the reference tree
+    (it uses the reference's own enums.hpp / domains.hpp): check that it does."""
+    import subprocess
+    src = tmp_path / "adapter_check.cpp"
+    src.write_text('#include "lk_cuda_class_adapter.hpp"\n'
+                   "int main() { HipCudaClass c; frame_results fr{}; float g[6] = {0};\n"
+                   "  c.set_fitting_model(fm_UVUxUyVxVy); c.set_interpolation_model(im_bicubic);\n"
+                   "  CorrelationResult *r = c.correlate(0, g, fr); v_points p = c.getUndXY0ToCPU(0);\n"
+                   "  return (int)p.size() + (int)r->errorCode + (int)c.resetPolygon(0, 1, 2, 3, 4); }\n")
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        "-I", "/root/reference", "-c", str(src), "-o", str(tmp_path / "a.o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
