@@ -48,6 +48,8 @@ int n_params_of(int model) {
 struct DevImage {
   uint8_t *lvl[LK_MAX_LEVELS] = {};
   size_t cap[LK_MAX_LEVELS] = {};
+  int guard_rows[LK_MAX_LEVELS] = {-1, -1, -1, -1, -1, -1, -1, -1}; // geometry the guard rows were zeroed for
+  int guard_cols[LK_MAX_LEVELS] = {-1, -1, -1, -1, -1, -1, -1, -1};
   int rows = 0, cols = 0;
   bool valid = false;
 };
@@ -287,9 +289,15 @@ static int set_image_common(lk_engine *e, int slot, const void *src, bool src_on
       }
       HIPCHK(hipMalloc((void **)&im.lvl[l], need));
       im.cap[l] = need;
+      im.guard_rows[l] = -1;
     }
-    // guard rows (and the whole level: the pyramid kernel writes every target pixel)
-    HIPCHK(hipMemsetAsync(im.lvl[l] + (size_t)r * (size_t)c, 0, 2 * (size_t)c + 16, st));
+    // two zeroed guard rows below the image; the pyramid kernel writes every target pixel
+    // itself, so this is only redone when the geometry of the level changes
+    if (im.guard_rows[l] != r || im.guard_cols[l] != c) {
+      HIPCHK(hipMemsetAsync(im.lvl[l] + (size_t)r * (size_t)c, 0, 2 * (size_t)c + 16, st));
+      im.guard_rows[l] = r;
+      im.guard_cols[l] = c;
+    }
     r /= 2;
     c /= 2;
   }
