@@ -28,8 +28,10 @@ struct LkSolveArgs {
   float *last_p;         // [S][6] copy of the returned parameters (sequence state), may be null
   uint32_t *stats;       // [S][4]: evaluations, sample evaluations, point iterations, -
   const uint32_t *order; // optional [n_sectors] indirection (size classes), may be null
-  uint32_t *queue;       // one counter: next unclaimed slot of this launch (zeroed per launch)
+  uint32_t *queue;       // next unclaimed slot of this launch (persistent mode), zeroed per launch
   int n_sectors;         // sectors in this launch
+  int chunk;             // non-persistent: ceil(#workgroups / 8), XCD-contiguous chunk length
+  int persistent;        // 1: groups pull sectors from `queue`; 0: one sector per group by position
   int py_start, py_step, py_stop;
   float precision;
   int max_iters;

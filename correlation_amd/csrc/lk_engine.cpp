@@ -644,7 +644,7 @@ int lk_commit_sectors(lk_engine *e) {
   HIPCHK(e->d_order.ensure((size_t)S));
   HIPCHK(hipMemcpy(e->d_order.p, e->h_order.data(), (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice));
   HIPCHK(e->d_single.ensure(1));
-  HIPCHK(e->d_queue.ensure(kNumClasses));
+  HIPCHK(e->d_queue.ensure(8 * kNumClasses));
   HIPCHK(e->d_scratch.ensure(64));
   e->S = S;
   e->committed = true;
@@ -786,7 +786,7 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
     LkSolveArgs a = base_args(e, d_guess, d_result);
     a.order = e->d_order.p + e->class_begin[c];
     a.n_sectors = n;
-    a.queue = e->d_queue.p + c;
+    a.queue = e->d_queue.p + 8 * c;
     HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, kGroupOfClass[c], e->stream));
   }
   HIPCHK(hipEventRecord(e->ev_s1, e->stream));

@@ -18,7 +18,7 @@
 // This translation unit is compiled with -ffp-contract=off: the reference's x86-64 builds
 // have no FMA, and per-sample values (warp, bicubic value/gradient, residual, H) are kept
 // bit-identical to that arithmetic.  FMAs appear only where they are provably exact
-// (the bicubic coefficient build, see bicubic_coeffs) or where only the summation order
+// (the bicubic coefficient build, see bicubic_sample) or where only the summation order
 // already differs from the reference (the A/b/chi accumulators).
 #include "lk_device.hpp"
 
@@ -77,36 +77,30 @@ __device__ __forceinline__ void cubic_1d(float p0, float p1, float p2, float p3,
   c3 = __builtin_fmaf(-0.5f, p0, __builtin_fmaf(1.5f, p1, __builtin_fmaf(-1.5f, p2, 0.5f * p3)));
 }
 
-// a[4*jk+ik]; def points at the level's image, pitch = cols
-__device__ __forceinline__ void bicubic_coeffs(gptr<uint8_t> def, int cols, int ix, int iy,
-                                               float (&a)[16]) {
+// Value and gradient of the bicubic at (ix + dx - 1, iy + dy - 1), dx,dy in [1,2).
+// The four coefficients of monomial row jk are produced (exactly, see above) right before
+// they are consumed, so only the 16 x-transformed values stay live, and then W, dW/dx,
+// dW/dy are accumulated in the reference's order (:94-126): three running sums, jk outer /
+// ik inner, each term built left to right.
+__device__ __forceinline__ void bicubic_sample(gptr<uint8_t> def, int cols, int ix, int iy, float dx,
+                                               float dy, float &W, float &Wx, float &Wy) {
   gptr<uint8_t> base = def + (size_t)(iy - 1) * (size_t)cols + (size_t)(ix - 1);
-#ifdef LK_EXP_NOLOAD
-  uint32_t r0 = (uint32_t)(ix * 2654435761u), r1 = r0 ^ (uint32_t)iy, r2 = r1 * 31u, r3 = r2 + 7u;
-  (void)base;
-#else
   uint32_t r0 = load_u32_unaligned(base);
   uint32_t r1 = load_u32_unaligned(base + cols);
   uint32_t r2 = load_u32_unaligned(base + 2 * (size_t)cols);
   uint32_t r3 = load_u32_unaligned(base + 3 * (size_t)cols);
-#endif
   // t[r][k]: x-direction transform of image row r
   float t0[4], t1[4], t2[4], t3[4];
   cubic_1d(ub0(r0), ub1(r0), ub2(r0), ub3(r0), t0[0], t0[1], t0[2], t0[3]);
   cubic_1d(ub0(r1), ub1(r1), ub2(r1), ub3(r1), t1[0], t1[1], t1[2], t1[3]);
   cubic_1d(ub0(r2), ub1(r2), ub2(r2), ub3(r2), t2[0], t2[1], t2[2], t2[3]);
   cubic_1d(ub0(r3), ub1(r3), ub2(r3), ub3(r3), t3[0], t3[1], t3[2], t3[3]);
-#pragma unroll
-  for (int ik = 0; ik < 4; ++ik) // y-direction transform of column ik
-    cubic_1d(t0[ik], t1[ik], t2[ik], t3[ik], a[0 + ik], a[4 + ik], a[8 + ik], a[12 + ik]);
-}
-
-// W, dW/dx, dW/dy with the reference's monomial evaluation order (:94-126): three
-// running sums, jk outer / ik inner, each term built left to right.
-__device__ __forceinline__ void bicubic_eval(const float (&a)[16], float dx, float dy, float &W,
-                                             float &Wx, float &Wy) {
-  float px[4] = {1.f, dx, dx * dx, dx * dx * dx};
-  float py[4] = {1.f, dy, dy * dy, dy * dy * dy};
+  constexpr float Cm[4][4] = {{2.0f, -3.0f, 3.0f, -1.0f},
+                              {-4.0f, 9.5f, -8.0f, 2.5f},
+                              {2.5f, -7.0f, 6.5f, -2.0f},
+                              {-0.5f, 1.5f, -1.5f, 0.5f}};
+  const float px[4] = {1.f, dx, dx * dx, dx * dx * dx};
+  const float py[4] = {1.f, dy, dy * dy, dy * dy * dy};
   W = 0.f;
   Wx = 0.f;
   Wy = 0.f;
@@ -114,7 +108,10 @@ __device__ __forceinline__ void bicubic_eval(const float (&a)[16], float dx, flo
   for (int jk = 0; jk < 4; ++jk) {
 #pragma unroll
     for (int ik = 0; ik < 4; ++ik) {
-      float c = a[jk * 4 + ik];
+      // y-direction transform, coefficient a[jk][ik] (exact in any order)
+      const float c = __builtin_fmaf(
+          Cm[jk][0], t0[ik],
+          __builtin_fmaf(Cm[jk][1], t1[ik], __builtin_fmaf(Cm[jk][2], t2[ik], Cm[jk][3] * t3[ik])));
       W += c * py[jk] * px[ik];
       if (ik > 0)
         Wx += (float)ik * c * py[jk] * px[ik - 1];
@@ -132,10 +129,8 @@ __device__ __forceinline__ bool sample_def(gptr<uint8_t> def, int rows, int cols
     if (!(xd > 1.f && yd > 1.f && xd < (float)cols - 2.f && yd < (float)rows - 2.f))
       return false;
     int ix = (int)xd, iy = (int)yd;
-    float a[16];
-    bicubic_coeffs(def, cols, ix, iy, a);
     float dx = xd - (float)ix + 1.f, dy = yd - (float)iy + 1.f;
-    bicubic_eval(a, dx, dy, W, Wx, Wy);
+    bicubic_sample(def, cols, ix, iy, dx, dy, W, Wx, Wy);
     return true;
   } else if constexpr (INTERP == LK_IM_BILINEAR) { // :140-195, :338-374
     if (!(xd > 0.f && yd > 0.f && xd < (float)(cols - 1) && yd < (float)(rows - 1)))
@@ -304,11 +299,7 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
     int uix = (int)(q.x + 0.5f), uiy = (int)(q.y + 0.5f);
     uix = min(max(uix, 0), umaxc); // memory safety only; valid sample lists never clamp
     uiy = min(max(uiy, 0), umaxr);
-#ifdef LK_EXP_NOLOAD
-    float und_w = (float)((uix * 7 + uiy * 13) & 255);
-#else
     float und_w = (float)c.und[(size_t)uiy * (size_t)c.ucols + (size_t)uix];
-#endif
     float W, Wx, Wy;
     if (!sample_def<INTERP>(c.def, c.drows, c.dcols, xd, yd, W, Wx, Wy)) {
       bad = true;
@@ -476,15 +467,22 @@ template <int P> __device__ __forceinline__ void translate(float (&p)[6], int sr
 //   TENT    evaluation of the tentative parameters + look-ahead solve (:503-529)
 //   REEVAL  reject path: re-evaluate at last_good with the larger lambda (:475-499)
 // GROUP == THREADS (64, 256, 512): one sector per workgroup, control flow is uniform.
-// Work distribution: the launch is PERSISTENT.  Each lane group pulls the next sector from
-// a device-wide queue (one returning atomic per sector) when it has finished its current
-// one, so wavefronts stay full until the queue is empty whatever the per-sector iteration
-// counts are.  A group that finds the queue empty idles (n = 0) until its wavefront's other
-// groups are done; every wave reaches the exit test after each step, so the grid drains.
+// Work distribution.  When there are many more sectors than resident lane groups the launch
+// is PERSISTENT: each group pulls the next sector from a device-wide queue (one returning
+// atomic per sector) when it has finished its current one, so wavefronts stay full until
+// the queue is empty whatever the per-sector iteration counts are.  A group that finds the
+// queue empty idles (n = 0) until its wavefront's other groups are done; every wave reaches
+// the exit test after each step, so the grid drains.  With fewer than ~2 sectors per
+// resident group a queue cannot balance anything (it only leaves half-empty wavefronts
+// behind); then one wavefront per 64/GROUP sectors is launched and the hardware dispatcher
+// fills freed slots with whole wavefronts (measured on C2: 0.33 vs 0.37 ms).
 enum : int { PH_EVAL0 = 0, PH_TENT = 1, PH_REEVAL = 2, PH_FETCH = 3, PH_EXIT = 4 };
 
+#ifndef LK_MIN_WAVES
+#define LK_MIN_WAVES 1
+#endif
 template <int MODEL, int INTERP, int GROUP, int THREADS>
-__global__ void __launch_bounds__(THREADS) lk_solve_kernel(LkSolveArgs a) {
+__global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) lk_solve_kernel(LkSolveArgs a) {
   constexpr int P = n_params(MODEL);
   using SumsT = Sums<P>;
   __shared__ float lds[GROUP > kWave ? (THREADS / kWave) * (SumsT::N + 1) + 1 : 1];
@@ -501,7 +499,7 @@ __global__ void __launch_bounds__(THREADS) lk_solve_kernel(LkSolveArgs a) {
   int level = a.py_stop, level_old = 0;
   int s = 0; // sector owned by this lane group
   float2 c0 = make_float2(0.f, 0.f);
-  bool use_saved = true;
+  bool use_saved = true, first_fetch = true;
   int phase = PH_FETCH;
   LevelCtx c{};
   SumsT S;
@@ -567,7 +565,13 @@ __global__ void __launch_bounds__(THREADS) lk_solve_kernel(LkSolveArgs a) {
   for (;;) {
     if (phase == PH_FETCH) { // pull the next sector
       int slot = 0;
-      if constexpr (GROUP > kWave) {
+      if (!a.persistent) { // one sector per group, handed out by position (see launch_solve_g)
+        // workgroups are dealt round-robin over the 8 XCDs: give each XCD one contiguous run
+        // of sectors (neighbouring sectors share image rows in its L2)
+        const int wg_slot = ((int)blockIdx.x & 7) * a.chunk + ((int)blockIdx.x >> 3);
+        slot = first_fetch ? wg_slot * (THREADS / GROUP) + (int)threadIdx.x / GROUP : a.n_sectors;
+        first_fetch = false;
+      } else if constexpr (GROUP > kWave) {
         __syncthreads(); // everybody is done reading lds from the last evaluation
         if (threadIdx.x == 0)
           reinterpret_cast<int *>(lds)[(THREADS / kWave) * (SumsT::N + 1)] = (int)atomicAdd(a.queue, 1u);
@@ -904,8 +908,11 @@ static hipError_t launch_solve_g(const LkSolveArgs &a, hipStream_t st) {
     resident = resident_workgroups(lk_solve_kernel<MODEL, INTERP, GROUP, THREADS>, THREADS);
   const int per_wg = THREADS / GROUP;
   const int want = (a.n_sectors + per_wg - 1) / per_wg;
-  dim3 grid((unsigned)(want < resident ? want : resident));
-  hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, GROUP, THREADS>), grid, dim3(THREADS), 0, st, a);
+  LkSolveArgs b = a;
+  b.persistent = want > 2 * resident ? 1 : 0;
+  b.chunk = (want + 7) / 8;
+  dim3 grid((unsigned)(b.persistent ? resident : 8 * b.chunk));
+  hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, GROUP, THREADS>), grid, dim3(THREADS), 0, st, b);
   return hipGetLastError();
 }
 
