@@ -478,6 +478,45 @@ template <int P> __device__ __forceinline__ void translate(float (&p)[6], int sr
 // fills freed slots with whole wavefronts (measured on C2: 0.33 vs 0.37 ms).
 enum : int { PH_EVAL0 = 0, PH_TENT = 1, PH_REEVAL = 2, PH_FETCH = 3, PH_EXIT = 4 };
 
+// Per-sector state that is only touched between evaluations ("cold": last-good parameters,
+// damping, counters, ...).  For the small lane groups it lives in LDS - every lane of a group
+// reads and writes the same words, in program order within one wavefront - which keeps ~20
+// registers out of the sample loop and the kernel at 4 wavefronts per SIMD.  Workgroup-wide
+// groups have registers to spare and keep it there.
+struct Cold {
+  float lg_p[6];
+  float lambda, lg_chi, c0x, c0y;
+  int iteration, reached, error, level, level_old, s, use_saved;
+  uint32_t n_evals, n_sample_evals, n_point_iters;
+};
+constexpr int kColdWords = sizeof(Cold) / 4;
+
+template <bool IN_LDS> struct ColdStore {
+  Cold reg;
+  __device__ __forceinline__ Cold load(const uint32_t *slot) const {
+    if constexpr (IN_LDS) {
+      Cold k;
+      uint32_t *w = reinterpret_cast<uint32_t *>(&k);
+#pragma unroll
+      for (int i = 0; i < kColdWords; ++i)
+        w[i] = slot[i];
+      return k;
+    } else {
+      return reg;
+    }
+  }
+  __device__ __forceinline__ void store(uint32_t *slot, const Cold &k) {
+    if constexpr (IN_LDS) {
+      const uint32_t *w = reinterpret_cast<const uint32_t *>(&k);
+#pragma unroll
+      for (int i = 0; i < kColdWords; ++i)
+        slot[i] = w[i];
+    } else {
+      reg = k;
+    }
+  }
+};
+
 #ifndef LK_MIN_WAVES
 #define LK_MIN_WAVES 1
 #endif
@@ -485,37 +524,35 @@ template <int MODEL, int INTERP, int GROUP, int THREADS>
 __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) lk_solve_kernel(LkSolveArgs a) {
   constexpr int P = n_params(MODEL);
   using SumsT = Sums<P>;
-  __shared__ float lds[GROUP > kWave ? (THREADS / kWave) * (SumsT::N + 1) + 1 : 1];
+  constexpr bool COLD_IN_LDS = GROUP <= kWave;
+  constexpr int RED_WORDS = GROUP > kWave ? (THREADS / kWave) * (SumsT::N + 1) + 1 : 1;
+  __shared__ float lds[RED_WORDS];
+  __shared__ uint32_t cold_lds[COLD_IN_LDS ? (THREADS / GROUP) * kColdWords : 1];
+  uint32_t *const cold_slot = cold_lds + (COLD_IN_LDS ? ((int)threadIdx.x / GROUP) * kColdWords : 0);
+  ColdStore<COLD_IN_LDS> cold;
 
-  float p[6], lg_p[6], tent[6];
+  float p[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i)
-    p[i] = lg_p[i] = tent[i] = 0.f;
+    p[i] = 0.f;
   const float min_lambda = 1e-9f, max_lambda = 1e9f;
-  float last_good_chi = FLT_MAX, lambda = 0.0001f;
-  int reached_iterations = 0, iteration = 0;
-  int error_code = LK_ERROR_NONE;
-  uint32_t n_evals = 0, n_sample_evals = 0, n_point_iters = 0;
-  int level = a.py_stop, level_old = 0;
-  int s = 0; // sector owned by this lane group
-  float2 c0 = make_float2(0.f, 0.f);
-  bool use_saved = true, first_fetch = true;
+  bool first_fetch = true;
   int phase = PH_FETCH;
   LevelCtx c{};
   SumsT S;
 
-  auto enter_level = [&]() { // top of the level loop (:373-408)
-    const LkLevelView lv = a.lv[level];
-    translate<P>(p, level_old, level);
-    error_code = LK_ERROR_NONE;
-    lambda = 0.0001f;
-    last_good_chi = FLT_MAX;
-    const uint32_t off = lv.off[s];
-    const int4 rc = lv.rect[s];
+  auto enter_level = [&](Cold &k) { // top of the level loop (:373-408)
+    const LkLevelView lv = a.lv[k.level];
+    translate<P>(p, k.level_old, k.level);
+    k.error = LK_ERROR_NONE;
+    k.lambda = 0.0001f;
+    k.lg_chi = FLT_MAX;
+    const uint32_t off = lv.off[k.s];
+    const int4 rc = lv.rect[k.s];
     c.rx = rc.x;
     c.ry = rc.y;
     c.rw = rc.z;
-    c.n = rc.z > 0 ? rc.w : (int)(lv.off[s + 1] - off);
+    c.n = rc.z > 0 ? rc.w : (int)(lv.off[k.s + 1] - off);
     c.und = (gptr<uint8_t>)lv.und;
     c.def = (gptr<uint8_t>)lv.def;
     c.xy = (gptr<f32x2>)(lv.xy + off);
@@ -524,46 +561,46 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
     c.drows = lv.drows;
     c.dcols = lv.dcols;
     c.scaling = 1.f / ((float)c.n);
-    const float inv = 1.f / (float)(1 << level); // pyramid_class.cpp:357-361
-    c.cx = level == 0 ? c0.x : c0.x * inv;
-    c.cy = level == 0 ? c0.y : c0.y * inv;
+    const float inv = 1.f / (float)(1 << k.level); // pyramid_class.cpp:357-361
+    c.cx = k.level == 0 ? k.c0x : k.c0x * inv;
+    c.cy = k.level == 0 ? k.c0y : k.c0y * inv;
 #pragma unroll
     for (int i = 0; i < P; ++i)
-      lg_p[i] = p[i];
+      k.lg_p[i] = p[i];
     phase = PH_EVAL0;
   };
 
-  auto finish_sector = [&]() { // results of Newton_Raphson (:638-639, :848-870)
+  auto finish_sector = [&](const Cold &k) { // results of Newton_Raphson (:638-639, :848-870)
     if ((int)threadIdx.x % GROUP == 0) {
       lk_result r;
 #pragma unroll
       for (int i = 0; i < 6; ++i)
         r.resultingParameters[i] = i < P ? p[i] : 0.f;
-      r.chi = last_good_chi;
-      const int4 rc0 = a.lv[0].rect[s];
-      r.numberOfPoints = rc0.z > 0 ? rc0.w : (int)(a.lv[0].off[s + 1] - a.lv[0].off[s]);
-      r.iterations = reached_iterations;
-      r.errorCode = error_code;
-      r.undCenterX = c0.x;
-      r.undCenterY = c0.y;
-      a.result[s] = r;
+      r.chi = k.lg_chi;
+      const int4 rc0 = a.lv[0].rect[k.s];
+      r.numberOfPoints = rc0.z > 0 ? rc0.w : (int)(a.lv[0].off[k.s + 1] - a.lv[0].off[k.s]);
+      r.iterations = k.reached;
+      r.errorCode = k.error;
+      r.undCenterX = k.c0x;
+      r.undCenterY = k.c0y;
+      a.result[k.s] = r;
       if (a.last_p) {
 #pragma unroll
         for (int i = 0; i < 6; ++i)
-          a.last_p[(size_t)s * 6 + i] = r.resultingParameters[i];
+          a.last_p[(size_t)k.s * 6 + i] = r.resultingParameters[i];
       }
       if (a.stats) {
-        a.stats[(size_t)s * 4 + 0] = n_evals;
-        a.stats[(size_t)s * 4 + 1] = n_sample_evals;
-        a.stats[(size_t)s * 4 + 2] = n_point_iters;
-        a.stats[(size_t)s * 4 + 3] = 0;
+        a.stats[(size_t)k.s * 4 + 0] = k.n_evals;
+        a.stats[(size_t)k.s * 4 + 1] = k.n_sample_evals;
+        a.stats[(size_t)k.s * 4 + 2] = k.n_point_iters;
+        a.stats[(size_t)k.s * 4 + 3] = 0;
       }
     }
     phase = PH_FETCH;
   };
 
   for (;;) {
-    if (phase == PH_FETCH) { // pull the next sector
+    if (phase == PH_FETCH) { // take the next sector
       int slot = 0;
       if (!a.persistent) { // one sector per group, handed out by position (see launch_solve_g)
         // workgroups are dealt round-robin over the 8 XCDs: give each XCD one contiguous run
@@ -574,27 +611,28 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
       } else if constexpr (GROUP > kWave) {
         __syncthreads(); // everybody is done reading lds from the last evaluation
         if (threadIdx.x == 0)
-          reinterpret_cast<int *>(lds)[(THREADS / kWave) * (SumsT::N + 1)] = (int)atomicAdd(a.queue, 1u);
+          reinterpret_cast<int *>(lds)[RED_WORDS - 1] = (int)atomicAdd(a.queue, 1u);
         __syncthreads();
-        slot = reinterpret_cast<int *>(lds)[(THREADS / kWave) * (SumsT::N + 1)];
+        slot = reinterpret_cast<int *>(lds)[RED_WORDS - 1];
       } else {
         if ((int)threadIdx.x % GROUP == 0)
           slot = (int)atomicAdd(a.queue, 1u);
         slot = __shfl(slot, ((int)threadIdx.x & 63) & ~(GROUP - 1), 64);
       }
       if (slot < a.n_sectors) {
-        s = a.order ? (int)a.order[slot] : slot;
+        Cold k{};
+        k.s = a.order ? (int)a.order[slot] : slot;
 #pragma unroll
         for (int i = 0; i < 6; ++i)
-          p[i] = i < P ? a.guess[(size_t)s * 6 + i] : 0.f;
-        c0 = a.center[s];
-        reached_iterations = 0;
-        iteration = 0;
-        n_evals = n_sample_evals = n_point_iters = 0;
-        level = a.py_stop;
-        level_old = 0;
-        use_saved = true;
-        enter_level();
+          p[i] = i < P ? a.guess[(size_t)k.s * 6 + i] : 0.f;
+        const float2 c0 = a.center[k.s];
+        k.c0x = c0.x;
+        k.c0y = c0.y;
+        k.level = a.py_stop;
+        k.level_old = 0;
+        k.use_saved = 1;
+        enter_level(k);
+        cold.store(cold_slot, k);
       } else {
         phase = PH_EXIT;
       }
@@ -602,94 +640,98 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
     const bool active = phase < PH_FETCH;
     if constexpr (GROUP >= kWave) {
       if (!active)
-        break; // uniform over the workgroup: the queue is empty
+        break; // uniform over the workgroup: nothing left to do
     } else {
       if (__ballot(active) == 0ull)
-        break; // every group of this wavefront found the queue empty
+        break; // every group of this wavefront is out of work
     }
     LevelCtx ce = c;
     if (!active)
       ce.n = 0;
     const bool err = evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds);
     if (active) {
-      ++n_evals;
-      n_sample_evals += (uint32_t)c.n;
-      bool level_end = false, iter_start = false;
+      Cold k = cold.load(cold_slot);
+      ++k.n_evals;
+      k.n_sample_evals += (uint32_t)c.n;
+      bool level_end = false, iter_start = false, finished = false;
       if (err) { // :413-419 (evaluation #0: return at once), :484-489, :511-516 (break)
-        error_code = LK_ERROR_INTERPOLATION_OUT_OF_IMAGE;
+        k.error = LK_ERROR_INTERPOLATION_OUT_OF_IMAGE;
         if (phase == PH_EVAL0) {
-          ++n_point_iters;
-          translate<P>(p, level, 0);
-          finish_sector();
+          ++k.n_point_iters;
+          translate<P>(p, k.level, 0);
+          finished = true;
         } else {
           level_end = true;
         }
       } else {
         const float chi = S.v[SumsT::N - 1] * c.scaling;
-        const float lam_use = phase == PH_TENT ? fmaxf(lambda * 0.4f, min_lambda) : lambda;
-        if (phase == PH_TENT) {
+        const float lam_use = phase == PH_TENT ? fmaxf(k.lambda * 0.4f, min_lambda) : k.lambda;
+        float tent[P]; // the parameters this evaluation ran at
 #pragma unroll
-          for (int i = 0; i < P; ++i)
-            tent[i] = p[i];
-        }
+        for (int i = 0; i < P; ++i)
+          tent[i] = p[i];
         damped_step<P>(S, lam_use, c.scaling, p); // p += dp (compute_model_parameters)
         if (phase == PH_EVAL0) {
-          ++n_point_iters;
-          last_good_chi = chi;
-          use_saved = true;
-          iteration = 1;
+          ++k.n_point_iters;
+          k.lg_chi = chi;
+          k.use_saved = 1;
+          k.iteration = 1;
           iter_start = true;
         } else if (phase == PH_REEVAL) {
           phase = PH_TENT; // p now holds the tentative parameters
         } else {           // PH_TENT: p now holds the look-ahead ("saved") parameters
           const float delta_chi =
-              __builtin_fabsf((last_good_chi - chi) / (fmaxf(last_good_chi, chi) + a.precision));
-          if (chi <= last_good_chi) {
-            last_good_chi = chi;
-            lambda = fmaxf(lambda * 0.4f, min_lambda);
+              __builtin_fabsf((k.lg_chi - chi) / (fmaxf(k.lg_chi, chi) + a.precision));
+          if (chi <= k.lg_chi) {
+            k.lg_chi = chi;
+            k.lambda = fmaxf(k.lambda * 0.4f, min_lambda);
 #pragma unroll
             for (int i = 0; i < P; ++i)
-              lg_p[i] = tent[i];
-            use_saved = true;
+              k.lg_p[i] = tent[i];
+            k.use_saved = 1;
           } else {
-            lambda = fminf(lambda * 10.0f, max_lambda);
-            use_saved = false;
+            k.lambda = fminf(k.lambda * 10.0f, max_lambda);
+            k.use_saved = 0;
           }
           if (delta_chi < a.precision) {
             level_end = true;
           } else {
-            ++iteration;
+            ++k.iteration;
             iter_start = true;
           }
         }
       }
       if (iter_start) { // top of the iteration loop (:441-499)
-        if (iteration > a.max_iters || lambda >= max_lambda) {
-          error_code = LK_ERROR_CORRELATION_MAX_ITERS_REACHED;
+        if (k.iteration > a.max_iters || k.lambda >= max_lambda) {
+          k.error = LK_ERROR_CORRELATION_MAX_ITERS_REACHED;
           level_end = true;
         } else {
-          reached_iterations = iteration;
-          ++n_point_iters;
-          if (use_saved) {
+          k.reached = k.iteration;
+          ++k.n_point_iters;
+          if (k.use_saved) {
             phase = PH_TENT; // tentative = saved = p
           } else {
 #pragma unroll
             for (int i = 0; i < P; ++i)
-              p[i] = lg_p[i];
+              p[i] = k.lg_p[i];
             phase = PH_REEVAL;
           }
         }
       }
       if (level_end) { // :589-591, :638
-        level_old = level;
-        level -= a.py_step;
-        if (level < a.py_start) {
-          translate<P>(p, level_old, 0);
-          finish_sector();
+        k.level_old = k.level;
+        k.level -= a.py_step;
+        if (k.level < a.py_start) {
+          translate<P>(p, k.level_old, 0);
+          finished = true;
         } else {
-          enter_level();
+          enter_level(k);
         }
       }
+      if (finished)
+        finish_sector(k);
+      else
+        cold.store(cold_slot, k);
     }
   }
 }
