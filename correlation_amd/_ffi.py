@@ -82,7 +82,7 @@ SYMBOLS = {
     "lk_get_guesses": (C.c_int, [_P, _F]),
     "lk_evaluate": (C.c_int, [_P, C.c_int, C.c_int, _F, _F, _F, _F, _I]),
     "lk_sample": (C.c_int, [_P, C.c_int, C.c_int, _F, C.c_int, _F]),
-    "lk_damped_solve": (C.c_int, [_P, C.c_int, _F, _F, C.c_float, C.c_float, _F]),
+    "lk_damped_solve": (C.c_int, [_P, C.c_int, _F, _F, C.c_float, C.c_float, C.c_int, _F]),
     "lk_get_stats": (C.c_int, [_P, C.POINTER(LkStats)]),
 }
 

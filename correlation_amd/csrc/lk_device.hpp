@@ -31,6 +31,7 @@ struct LkSolveArgs {
   uint32_t *queue;       // next unclaimed slot of this launch (persistent mode), zeroed per launch
   int n_sectors;         // sectors in this launch
   int chunk;             // non-persistent: ceil(#workgroups / 8), XCD-contiguous chunk length
+  int safe;              // 1: reference-exact handling of starved / ill-conditioned levels
   int persistent;        // 1: groups pull sectors from `queue`; 0: one sector per group by position
   int py_start, py_step, py_stop;
   float precision;

@@ -138,6 +138,7 @@ struct lk_engine {
   DevBuf<uint32_t> d_order;
   std::vector<uint32_t> h_order; // sectors grouped by size class
   int class_begin[kNumClasses + 1] = {0, 0, 0, 0, 0, 0};
+  bool class_safe[kNumClasses] = {false, false, false, false, false}; // a sector of the class has a starved level
   std::vector<int> h_class; // size class of every sector
   DevBuf<uint32_t> d_single, d_queue;
   DevBuf<float> d_scratch; // 64 floats for the stand-alone entry points
@@ -641,6 +642,24 @@ int lk_commit_sectors(lk_engine *e) {
         e->h_order.push_back((uint32_t)s);
   }
   e->class_begin[kNumClasses] = (int)e->h_order.size();
+  // starved levels (at most 2P samples for P parameters) need the reference-exact flavour
+  for (int c = 0; c < kNumClasses; ++c)
+    e->class_safe[c] = false;
+  if (const char *f = std::getenv("LK_FORCE_SAFE")) { // tuning / test hook
+    for (int c = 0; c < kNumClasses; ++c)
+      e->class_safe[c] = std::atoi(f) != 0;
+  } else {
+    for (int l : levels) {
+      if (l < cfg.py_start)
+        continue;
+      for (int s = 0; s < S; ++s) {
+        const int4 r = e->h_rect[l][(size_t)s];
+        const int n = r.z > 0 ? r.w : (int)(e->h_off[l][(size_t)s + 1] - e->h_off[l][(size_t)s]);
+        if (n <= 2 * e->P)
+          e->class_safe[e->h_class[(size_t)s]] = true;
+      }
+    }
+  }
   HIPCHK(e->d_order.ensure((size_t)S));
   HIPCHK(hipMemcpy(e->d_order.p, e->h_order.data(), (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice));
   HIPCHK(e->d_single.ensure(1));
@@ -787,6 +806,7 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
     a.order = e->d_order.p + e->class_begin[c];
     a.n_sectors = n;
     a.queue = e->d_queue.p + 8 * c;
+    a.safe = e->class_safe[c] ? 1 : 0;
     HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, kGroupOfClass[c], e->stream));
   }
   HIPCHK(hipEventRecord(e->ev_s1, e->stream));
@@ -851,6 +871,7 @@ int lk_correlate(lk_engine *e, int sector, float *guess_inout, lk_result *out) {
   const int group = kGroupOfClass[e->h_class[(size_t)sector]];
   a.n_sectors = 1;
   a.queue = e->d_queue.p;
+  a.safe = e->class_safe[e->h_class[(size_t)sector]] ? 1 : 0;
   HIPCHK(hipEventRecord(e->ev_s0, e->stream));
   HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, group, e->stream));
   HIPCHK(hipEventRecord(e->ev_s1, e->stream));
@@ -955,14 +976,14 @@ int lk_sample(lk_engine *e, int slot, int level, const float *xy, int n, float *
 }
 
 int lk_damped_solve(lk_engine *e, int n, const float *A, const float *b, float lambda, float scaling,
-                    float *dp) {
+                    int reference_solver, float *dp) {
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
   if (!(n == 1 || n == 2 || n == 3 || n == 6) || !A || !b || !dp)
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_damped_solve: n must be 1, 2, 3 or 6");
   HIPCHK(hipSetDevice(e->cfg.device));
   HIPCHK(e->d_scratch.ensure(64));
-  float h[44];
+  float h[48];
   std::memset(h, 0, sizeof(h));
   for (int i = 0; i < n; ++i) {
     h[36 + i] = b[i];
@@ -971,6 +992,7 @@ int lk_damped_solve(lk_engine *e, int n, const float *A, const float *b, float l
   }
   h[42] = lambda;
   h[43] = scaling;
+  h[44] = reference_solver ? 1.f : 0.f;
   HIPCHK(hipMemcpyAsync(e->d_scratch.p, h, sizeof(h), hipMemcpyHostToDevice, e->stream));
   HIPCHK(lk_launch_solve_only(n, e->d_scratch.p, e->d_scratch.p + 48, e->stream));
   float o[6];

@@ -23,6 +23,7 @@
 #include "lk_device.hpp"
 
 #include <float.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -259,7 +260,7 @@ __device__ __forceinline__ float rows_sum(float v) { // after row16_sum: add the
   return (r0 + r1) + (r2 + r3);
 }
 
-template <int MODEL, int INTERP, int GROUP, int THREADS>
+template <int MODEL, int INTERP, int GROUP, int THREADS, bool SAFE>
 __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
                                          Sums<n_params(MODEL)> &S, float *lds) {
   constexpr int P = n_params(MODEL);
@@ -273,13 +274,23 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
   // pixels of one image row (a 16-lane group touches 1-2 cache lines per load instead of
   // 16).  The reference enumerates y-fastest (manager_class.cpp:1607-1611); only the float
   // summation order depends on that, and a parallel reduction does not keep it anyway.
+  //
+  // Starved levels (SAFE kernels only; at most 2P samples - fewer samples than parameters
+  // happen at the coarsest level of BASELINE config 5, 4-9 samples for 6 parameters) are
+  // the exception: there the 6x6
+  // system is (nearly) singular and the pivoted QR amplifies the last bit of A and b, so the
+  // sums themselves must be the reference's.  One sample per lane in the REFERENCE's
+  // order, then an ordered lane-by-lane sum (see below) gives bit-identical A, b, chi.
+  const bool tiny = SAFE && c.n <= 2 * P; // starved: at most twice as many samples as parameters
   const float inv_w = c.rw > 0 ? 1.f / (float)c.rw : 0.f;
-#ifdef LK_EXP_UNROLL
-#pragma unroll LK_EXP_UNROLL
-#endif
+  const int rh = c.rw > 0 ? c.n / c.rw : 1; // height of the implicit rectangle
   for (int k = (int)threadIdx.x % GROUP; k < c.n; k += GROUP) {
     f32x2 q;
-    if (c.rw > 0) { // k -> (row, column) of the rectangle
+    if (c.rw > 0 && tiny) { // reference order: x outer, y inner (manager_class.cpp:1607-1611)
+      const int col = k / rh;
+      q.x = (float)(c.rx + col);
+      q.y = (float)(c.ry + (k - col * rh));
+    } else if (c.rw > 0) { // k -> (row, column) of the rectangle
       int row = (int)((float)k * inv_w);
       int col = k - row * c.rw;
       if (col < 0) {
@@ -320,23 +331,41 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
     S.v[SumsT::N - 1] = __builtin_fmaf(V, V, S.v[SumsT::N - 1]);
   }
   // reconverged: all 64 lanes of every wave are active from here on
-#pragma unroll
-  for (int i = 0; i < SumsT::N; ++i)
-    S.v[i] = row16_sum(S.v[i]);
   const unsigned long long badmask = __ballot(bad);
+  if (tiny) {
+    // each of the group's first n lanes holds the rounded products of ONE sample (fma(a,b,0)
+    // rounds once, like the reference's multiply); add them in sample order, as
+    // interpolation_class.cpp:722-749 does
+    const int base = ((int)threadIdx.x & 63) & ~(GROUP < kWave ? GROUP - 1 : kWave - 1);
+#pragma unroll
+    for (int i = 0; i < SumsT::N; ++i) {
+      float acc = 0.f;
+      for (int l = 0; l < c.n; ++l)
+        acc += __shfl(S.v[i], base + l, 64);
+      S.v[i] = acc;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < SumsT::N; ++i)
+      S.v[i] = row16_sum(S.v[i]);
+  }
   if constexpr (GROUP == 16) {
     const int row = ((int)threadIdx.x & 63) >> 4;
     return ((badmask >> (16 * row)) & 0xffffull) != 0ull;
   } else if constexpr (GROUP == 32) { // two sectors per wavefront: add the partner row
+    if (!tiny) {
 #pragma unroll
-    for (int i = 0; i < SumsT::N; ++i)
-      S.v[i] += __shfl_xor(S.v[i], 16, 64);
+      for (int i = 0; i < SumsT::N; ++i)
+        S.v[i] += __shfl_xor(S.v[i], 16, 64);
+    }
     const int half = ((int)threadIdx.x & 63) >> 5;
     return ((badmask >> (32 * half)) & 0xffffffffull) != 0ull;
   } else {
+    if (!tiny) { // (the ordered sum above already left the total in every lane)
 #pragma unroll
-    for (int i = 0; i < SumsT::N; ++i)
-      S.v[i] = rows_sum(S.v[i]);
+      for (int i = 0; i < SumsT::N; ++i)
+        S.v[i] = rows_sum(S.v[i]);
+    }
     bool any_bad = badmask != 0ull;
     if constexpr (GROUP > kWave) {
       constexpr int WAVES = THREADS / kWave;
@@ -372,19 +401,195 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
 // ------------------------------------------------------------------------------------
 // The reference hands the symmetric, LM-damped matrix to Eigen's ColPivHouseholderQR
 // (correlation_class.cpp:742-747); its CUDA path uses cuSOLVER's Cholesky instead
-// (cuda_solver.cu:120-149).  A = sum(H H^T)/n with the diagonal scaled by (1+lambda) is
-// symmetric positive (semi-)definite, so the engine factors it as U^T D U (root-free
-// Cholesky) entirely in registers: ~200 instructions per solve against ~3000 for a
-// register-resident pivoted Householder QR, with the same backward-stable O(cond*eps)
-// accuracy on SPD input.  A pivot that is not safely positive (flat, textureless sector)
-// zeroes that parameter's step, which is what the rank-revealing QR does with its
-// dropped pivots.  The difference to the QR result is far below the summation-order
-// noise of b (tests/test_parity_gpu.py docstring; scripts/parity_noise.py).
+// (cuda_solver.cu:120-149).  Two solvers live here:
 //
+//  * fast path - A = sum(H H^T)/n with the diagonal scaled by (1+lambda) is symmetric
+//    positive (semi-)definite; it is factored as U^T D U (root-free Cholesky) entirely in
+//    registers, ~200 instructions.  Used whenever every pivot is at least 1e-4 of the
+//    largest diagonal entry, i.e. the system is well conditioned and any backward-stable
+//    solver returns the same step to rounding (tests/test_parity_gpu.py docstring).
+//  * reference path - Eigen 3.4.0 ColPivHouseholderQR restated (column norms with
+//    LAPACK-style down-dating, first-largest remaining column as pivot, Householder
+//    reflectors, rank decision, back-substitution), ~3000 instructions.  Used when a pivot
+//    of the fast path is small or non-positive: few samples (fewer than parameters at a
+//    coarse pyramid level - BASELINE config 5's level 3 has 4-9 samples for 6 parameters),
+//    flat texture.  There the answer is DEFINED by the rank-revealing pivoting (dropped
+//    pivots get a zero step), so the engine follows it operation by operation.
+//    All indices are compile-time after unrolling; the pivot choice is applied with
+//    compare-and-swap so nothing is dynamically indexed (no scratch).  M is column-major.
+template <int N>
+__device__ __forceinline__ void colpiv_qr_solve(float (&M)[N * N], const float (&bin)[N],
+                                                float (&x)[N]) {
+#define QR(r, c) M[(c)*N + (r)]
+  float hc[N], normU[N], normD[N], cv[N];
+  int trans[N];
+  const float eps = FLT_EPSILON;
+  float maxn = 0.f;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+      s += QR(r, k) * QR(r, k);
+    normD[k] = __builtin_sqrtf(s);
+    normU[k] = normD[k];
+    if (normU[k] > maxn)
+      maxn = normU[k];
+  }
+  const float threshold_helper = (maxn * eps) * (maxn * eps) / (float)N;
+  const float norm_downdate_threshold = __builtin_sqrtf(eps);
+  int nonzero_pivots = N;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    int big = k;
+    float bigv = normU[k];
+#pragma unroll
+    for (int j = k + 1; j < N; ++j)
+      if (normU[j] > bigv) {
+        bigv = normU[j];
+        big = j;
+      }
+    float big_sq = bigv * bigv;
+    if (nonzero_pivots == N && big_sq < threshold_helper * (float)(N - k))
+      nonzero_pivots = k;
+    trans[k] = big;
+#pragma unroll
+    for (int j = k + 1; j < N; ++j) {
+      if (big == j) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+          float t = QR(r, k);
+          QR(r, k) = QR(r, j);
+          QR(r, j) = t;
+        }
+        float t = normU[k];
+        normU[k] = normU[j];
+        normU[j] = t;
+        t = normD[k];
+        normD[k] = normD[j];
+        normD[j] = t;
+      }
+    }
+    float tailSq = 0.f;
+#pragma unroll
+    for (int r = k + 1; r < N; ++r)
+      tailSq += QR(r, k) * QR(r, k);
+    float c0 = QR(k, k), beta, tau;
+    if (tailSq <= FLT_MIN) {
+      tau = 0.f;
+      beta = c0;
+#pragma unroll
+      for (int r = k + 1; r < N; ++r)
+        QR(r, k) = 0.f;
+    } else {
+      beta = __builtin_sqrtf(c0 * c0 + tailSq);
+      if (c0 >= 0.f)
+        beta = -beta;
+      float den = c0 - beta;
+#pragma unroll
+      for (int r = k + 1; r < N; ++r)
+        QR(r, k) = QR(r, k) / den;
+      tau = (beta - c0) / beta;
+    }
+    hc[k] = tau;
+    QR(k, k) = beta;
+    if (N - k > 1 && tau != 0.f) {
+#pragma unroll
+      for (int j = k + 1; j < N; ++j) {
+        float tmp = 0.f;
+#pragma unroll
+        for (int r = k + 1; r < N; ++r)
+          tmp += QR(r, k) * QR(r, j);
+        tmp += QR(k, j);
+        QR(k, j) -= tau * tmp;
+#pragma unroll
+        for (int r = k + 1; r < N; ++r)
+          QR(r, j) -= tmp * (tau * QR(r, k));
+      }
+    }
+#pragma unroll
+    for (int j = k + 1; j < N; ++j) {
+      if (normU[j] != 0.f) {
+        float temp = __builtin_fabsf(QR(k, j)) / normU[j];
+        temp = (1.f + temp) * (1.f - temp);
+        temp = temp < 0.f ? 0.f : temp;
+        float ratio = normU[j] / normD[j];
+        float temp2 = temp * (ratio * ratio);
+        if (temp2 <= norm_downdate_threshold) {
+          float s = 0.f;
+#pragma unroll
+          for (int r = k + 1; r < N; ++r)
+            s += QR(r, j) * QR(r, j);
+          normD[j] = __builtin_sqrtf(s);
+          normU[j] = normD[j];
+        } else {
+          normU[j] *= __builtin_sqrtf(temp);
+        }
+      }
+    }
+  }
+  if (nonzero_pivots == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      x[i] = 0.f;
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    cv[i] = bin[i];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (k < nonzero_pivots) {
+      if (N - k == 1) {
+        cv[k] *= 1.f - hc[k];
+      } else if (hc[k] != 0.f) {
+        float tmp = 0.f;
+#pragma unroll
+        for (int r = k + 1; r < N; ++r)
+          tmp += QR(r, k) * cv[r];
+        tmp += cv[k];
+        cv[k] -= hc[k] * tmp;
+#pragma unroll
+        for (int r = k + 1; r < N; ++r)
+          cv[r] -= tmp * (hc[k] * QR(r, k));
+      }
+    }
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    if (i < nonzero_pivots) {
+      cv[i] = cv[i] / QR(i, i);
+#pragma unroll
+      for (int r = 0; r < i; ++r)
+        cv[r] -= cv[i] * QR(r, i);
+    } else {
+      cv[i] = 0.f; // rank-deficient tail: dst rows of the dropped pivots are zero
+    }
+  }
+  // x[perm[i]] = cv[i], perm = product of the transpositions (k, trans[k]), applied on the
+  // right in ascending k.  Equivalent, without a dynamically indexed perm[]: start from
+  // y = cv and undo the column swaps in descending k.
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    x[i] = cv[i];
+#pragma unroll
+  for (int k = N - 1; k >= 0; --k) {
+#pragma unroll
+    for (int j = k + 1; j < N; ++j)
+      if (trans[k] == j) {
+        float t = x[k];
+        x[k] = x[j];
+        x[j] = t;
+      }
+  }
+#undef QR
+}
+
+
 // S holds the raw sums (upper triangle row-major, b, chi); p += dp.
-template <int P>
+template <int P, bool SAFE>
 __device__ __forceinline__ void damped_step(const Sums<P> &S, float lambda, float scaling,
-                                            float (&p)[6], float *dp_out = nullptr) {
+                                            float (&p)[6], bool starved, float *dp_out = nullptr) {
   // U[i][j], i <= j: starts as the scaled, damped upper triangle of A
   float U[P][P], d[P], inv_d[P], y[P], x[P];
   int idx = 0;
@@ -402,19 +607,26 @@ __device__ __forceinline__ void damped_step(const Sums<P> &S, float lambda, floa
     }
     y[i] = S.v[Sums<P>::NA + i] * scaling;
   }
-  const float tiny = dmax * 1e-7f;
+  // A pivot d_j is what remains of the diagonal entry after eliminating the earlier
+  // parameters; d_j / A_jj is scale free.  Healthy speckle gives >= 0.1; a damped singular
+  // system gives ~lambda.  Below 1e-3 the reference's pivoting decides the answer.
+  // A starved level (see evaluate<>) always takes the reference's solver: its sums are
+  // bit-identical to the reference's, so the whole trajectory is.
+  bool well_conditioned = !starved;
 #pragma unroll
   for (int j = 0; j < P; ++j) {
     float w[P > 1 ? P : 1];
-    float dj = U[j][j];
+    const float ajj = U[j][j];
+    float dj = ajj;
 #pragma unroll
     for (int k = 0; k < j; ++k) {
       w[k] = U[k][j] * d[k];
       dj = __builtin_fmaf(-U[k][j], w[k], dj);
     }
-    const bool ok = dj > tiny;
-    d[j] = ok ? dj : 0.f;
-    inv_d[j] = ok ? 1.f / dj : 0.f;
+    const bool ok = dj > ajj * 1e-3f && dj > dmax * 1e-7f; // false for NaN as well
+    well_conditioned = well_conditioned && ok;
+    d[j] = (SAFE || ok) ? dj : 0.f;
+    inv_d[j] = (SAFE || ok) ? 1.f / dj : 0.f; // fast flavour: a bad pivot zeroes that parameter's step
 #pragma unroll
     for (int i = j + 1; i < P; ++i) {
       float t = U[j][i];
@@ -424,20 +636,40 @@ __device__ __forceinline__ void damped_step(const Sums<P> &S, float lambda, floa
       U[j][i] = t * inv_d[j];
     }
   }
-  // U^T y' = b (forward), z = y'/d, U x = z (backward)
+  if (!SAFE || well_conditioned) {
+    // U^T y' = b (forward), z = y'/d, U x = z (backward)
 #pragma unroll
-  for (int j = 0; j < P; ++j) {
+    for (int j = 0; j < P; ++j) {
 #pragma unroll
-    for (int k = 0; k < j; ++k)
-      y[j] = __builtin_fmaf(-U[k][j], y[k], y[j]);
-  }
+      for (int k = 0; k < j; ++k)
+        y[j] = __builtin_fmaf(-U[k][j], y[k], y[j]);
+    }
 #pragma unroll
-  for (int j = P - 1; j >= 0; --j) {
-    float t = y[j] * inv_d[j];
+    for (int j = P - 1; j >= 0; --j) {
+      float t = y[j] * inv_d[j];
 #pragma unroll
-    for (int i = j + 1; i < P; ++i)
-      t = __builtin_fmaf(-U[j][i], x[i], t);
-    x[j] = t;
+      for (int i = j + 1; i < P; ++i)
+        t = __builtin_fmaf(-U[j][i], x[i], t);
+      x[j] = t;
+    }
+  } else if constexpr (SAFE) {
+    // rebuild the damped symmetric matrix exactly as the reference does (:647-665) and
+    // solve it the reference's way
+    float M[P * P], b[P];
+    int q = 0;
+#pragma unroll
+    for (int p1 = 0; p1 < P; ++p1) {
+      b[p1] = S.v[Sums<P>::NA + p1] * scaling;
+#pragma unroll
+      for (int p2 = p1; p2 < P; ++p2) {
+        float a = S.v[q++] * scaling;
+        if (p1 == p2)
+          a *= (1.f + lambda);
+        M[p1 * P + p2] = a;
+        M[p2 * P + p1] = a;
+      }
+    }
+    colpiv_qr_solve<P>(M, b, x);
   }
 #pragma unroll
   for (int i = 0; i < P; ++i) {
@@ -520,7 +752,7 @@ template <bool IN_LDS> struct ColdStore {
 #ifndef LK_MIN_WAVES
 #define LK_MIN_WAVES 1
 #endif
-template <int MODEL, int INTERP, int GROUP, int THREADS>
+template <int MODEL, int INTERP, int GROUP, int THREADS, bool SAFE>
 __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) lk_solve_kernel(LkSolveArgs a) {
   constexpr int P = n_params(MODEL);
   using SumsT = Sums<P>;
@@ -648,7 +880,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
     LevelCtx ce = c;
     if (!active)
       ce.n = 0;
-    const bool err = evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds);
+    const bool err = evaluate<MODEL, INTERP, GROUP, THREADS, SAFE>(ce, p, S, lds);
     if (active) {
       Cold k = cold.load(cold_slot);
       ++k.n_evals;
@@ -670,7 +902,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
 #pragma unroll
         for (int i = 0; i < P; ++i)
           tent[i] = p[i];
-        damped_step<P>(S, lam_use, c.scaling, p); // p += dp (compute_model_parameters)
+        damped_step<P, SAFE>(S, lam_use, c.scaling, p, c.n <= 2 * P); // p += dp (compute_model_parameters)
         if (phase == PH_EVAL0) {
           ++k.n_point_iters;
           k.lg_chi = chi;
@@ -768,7 +1000,7 @@ __global__ void __launch_bounds__(256) lk_eval_kernel(LkEvalArgs a) {
   for (int i = 0; i < 6; ++i)
     p[i] = a.p[i];
   SumsT S;
-  bool err = evaluate<MODEL, INTERP, GROUP, 256>(c, p, S, lds);
+  bool err = evaluate<MODEL, INTERP, GROUP, 256, true>(c, p, S, lds);
   if (threadIdx.x == 0) {
     for (int i = 0; i < 44; ++i)
       a.out[i] = 0.f;
@@ -807,7 +1039,7 @@ template <int P> __global__ void lk_solve_only_kernel(const float *in, float *dp
     S.v[Sums<P>::NA + p1] = in[36 + p1];
   S.v[Sums<P>::N - 1] = 0.f;
   float p[6] = {0, 0, 0, 0, 0, 0}, dp[6] = {0, 0, 0, 0, 0, 0};
-  damped_step<P>(S, in[42], in[43], p, dp);
+  damped_step<P, true>(S, in[42], in[43], p, in[44] != 0.f, dp);
   if (threadIdx.x == 0 && blockIdx.x == 0)
     for (int i = 0; i < 6; ++i)
       dp_out[i] = i < P ? dp[i] : 0.f;
@@ -943,19 +1175,32 @@ template <class K> static int resident_workgroups(K kernel, int threads) {
   return cus * per_cu;
 }
 
-template <int MODEL, int INTERP, int GROUP, int THREADS>
-static hipError_t launch_solve_g(const LkSolveArgs &a, hipStream_t st) {
+template <int MODEL, int INTERP, int GROUP, int THREADS, bool SAFE>
+static hipError_t launch_solve_gs(const LkSolveArgs &a, hipStream_t st) {
   static int resident = 0; // per template instance (one device type per process)
   if (resident == 0)
-    resident = resident_workgroups(lk_solve_kernel<MODEL, INTERP, GROUP, THREADS>, THREADS);
+    resident = resident_workgroups(lk_solve_kernel<MODEL, INTERP, GROUP, THREADS, SAFE>, THREADS);
   const int per_wg = THREADS / GROUP;
   const int want = (a.n_sectors + per_wg - 1) / per_wg;
   LkSolveArgs b = a;
-  b.persistent = want > 2 * resident ? 1 : 0;
+  static const int force_persistent = [] { // tuning / test hook
+    const char *f = getenv("LK_FORCE_PERSISTENT");
+    return f ? atoi(f) : -1;
+  }();
+  b.persistent = force_persistent >= 0 ? force_persistent : (want > 2 * resident ? 1 : 0);
   b.chunk = (want + 7) / 8;
   dim3 grid((unsigned)(b.persistent ? resident : 8 * b.chunk));
-  hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, GROUP, THREADS>), grid, dim3(THREADS), 0, st, b);
+  hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, GROUP, THREADS, SAFE>), grid, dim3(THREADS), 0, st, b);
   return hipGetLastError();
+}
+
+// SAFE flavour: starved levels are summed in the reference's order and ill-conditioned
+// systems go through the reference's pivoted QR (launched when a sector has a level with
+// at most 2P samples, a.safe); the fast flavour carries neither.
+template <int MODEL, int INTERP, int GROUP, int THREADS>
+static hipError_t launch_solve_g(const LkSolveArgs &a, hipStream_t st) {
+  return a.safe ? launch_solve_gs<MODEL, INTERP, GROUP, THREADS, true>(a, st)
+                : launch_solve_gs<MODEL, INTERP, GROUP, THREADS, false>(a, st);
 }
 
 template <int MODEL, int INTERP>

@@ -222,13 +222,13 @@ class HipCorrelationEngine:
         self._chk(self.lib.lk_sample(self._h, slot, level, _ffi.fptr(a), a.shape[0], _ffi.fptr(out)))
         return out
 
-    def damped_solve(self, A, b, lam, scaling):
+    def damped_solve(self, A, b, lam, scaling, reference_solver=False):
         A = np.ascontiguousarray(A, np.float32)
         n = A.shape[0]
         b = np.ascontiguousarray(b, np.float32)
         dp = np.zeros(n, np.float32)
         self._chk(self.lib.lk_damped_solve(self._h, n, _ffi.fptr(A), _ffi.fptr(b), lam, scaling,
-                                           _ffi.fptr(dp)))
+                                           int(reference_solver), _ffi.fptr(dp)))
         return dp
 
     def stats(self):

@@ -29,6 +29,31 @@ def _render(h, w, xs, ys, amps, sigma):
     return np.rint(img).astype(np.uint8).reshape(h, w)
 
 
+def _render_torch(h, w, xs, ys, amps, sigma, device):
+    """Same image as _render, accumulated in float64 on the GPU (large images)."""
+    import torch
+    img = torch.zeros(h * w, dtype=torch.float64, device=device)
+    xs_t = torch.from_numpy(xs).to(device)
+    ys_t = torch.from_numpy(ys).to(device)
+    am_t = torch.from_numpy(amps).to(device)
+    rad = int(np.ceil(4 * sigma))
+    x0 = torch.floor(xs_t).long()
+    y0 = torch.floor(ys_t).long()
+    inv = np.float32(-0.5 / (sigma * sigma))
+    for dy in range(-rad, rad + 2):
+        yy = y0 + dy
+        ey = (yy.float() - ys_t) ** 2
+        oky = (yy >= 0) & (yy < h)
+        for dx in range(-rad, rad + 2):
+            xx = x0 + dx
+            ok = oky & (xx >= 0) & (xx < w)
+            ex = (xx.float() - xs_t) ** 2
+            val = am_t * torch.exp((ex + ey) * inv)
+            img.index_add_(0, (yy * w + xx)[ok], val[ok].double())
+    img = torch.clamp(img.float(), max=1.0) * 255.0
+    return torch.round(img).to(torch.uint8).reshape(h, w).cpu().numpy()
+
+
 def blobs(h, w, seed=7, density=40):
     rng = np.random.default_rng(seed)
     n = (h * w) // density
@@ -46,11 +71,15 @@ def deform(xs, ys, h, w, p):
     return xs + u + ux * dx + uy * dy, ys + v + vx * dx + vy * dy
 
 
-def speckle_pair(h, w, p=(1.3, -0.7, 0.002, 0.0, 0.0, -0.001), seed=7, sigma=2.5):
-    """Returns (undeformed, deformed) u8 images of shape (h, w)."""
+def speckle_pair(h, w, p=(1.3, -0.7, 0.002, 0.0, 0.0, -0.001), seed=7, sigma=2.5, device=None):
+    """Returns (undeformed, deformed) u8 images of shape (h, w).  device="cuda" renders with
+    torch on the GPU (float64 accumulation; for the large configs)."""
     xs, ys, amps = blobs(h, w, seed)
-    und = _render(h, w, xs, ys, amps, sigma)
     xd, yd = deform(xs, ys, h, w, p)
+    if device is not None:
+        return (_render_torch(h, w, xs, ys, amps, sigma, device),
+                _render_torch(h, w, xd, yd, amps, sigma, device))
+    und = _render(h, w, xs, ys, amps, sigma)
     dfm = _render(h, w, xd, yd, amps, sigma)
     return und, dfm
 

@@ -183,9 +183,12 @@ int lk_evaluate(lk_engine *e, int sector, int level, const float *p, float *A36,
  * (InterpolationClass::get_interpolation, interpolation_class.cpp:79-226), with the
  * engine's interpolation model: out4[k] = {W, dW/dx, dW/dy, out_of_image ? 1 : 0} */
 int lk_sample(lk_engine *e, int slot, int level, const float *xy, int n, float *out4);
-/* compute_model_parameters + solve (correlation_class.cpp:642-768) on the device */
+/* compute_model_parameters + solve (correlation_class.cpp:642-768) on the device.
+ * reference_solver = 0: the engine's normal choice (root-free Cholesky, falling back to the
+ * reference's pivoted QR when a pivot is small); 1: the pivoted QR always, as the solve
+ * kernel does on starved pyramid levels (at most 2P samples) */
 int lk_damped_solve(lk_engine *e, int n, const float *A_rowmajor_upper, const float *b,
-                    float lambda, float scaling, float *dp);
+                    float lambda, float scaling, int reference_solver, float *dp);
 
 int lk_get_stats(lk_engine *e, lk_stats *out);
 

@@ -28,7 +28,8 @@ What is bit-exact and what cannot be
   solver is, not closer.
   So every Newton-Raphson comparison below checks the engine against oracle(T=1, QR) with
    (a) hard caps far below any real defect: 5e-3 px, 5e-5 on p2..p5, 5e-3 relative on chi,
-       iteration counts within 1 (but for 1 sector in 200);
+       iteration counts within 1 (but for 1 sector in 200) - relaxed to 3x the yardsticks'
+       own maxima where those are larger (starved configurations);
    (b) the strict tolerances of SURVEY.md 8c (1e-4 px on p0,p1; 1e-6 on p2..p5; chi rel
        1e-5; same iteration count) on at least as large a fraction of sectors as the
        yardsticks reach on the same sectors: oracle(T=8, QR) - the reference against itself
@@ -110,11 +111,25 @@ def compare_results(got, want_pair, label=""):
         return 1.0, 1.0
     dp = np.abs(g["p"] - w["p"])
     chi_rel = np.abs(g["chi"] - w["chi"]) / np.maximum(np.abs(w["chi"]), 1e-30)
+    # caps: far below any real defect, but never tighter than 3x what the yardstick runs
+    # themselves show on these sectors (starved configurations are chaotic for everybody)
+    def yard(field):
+        out = 0.0
+        for y in (s8, ex):
+            if field == "chi":
+                out = max(out, float((np.abs(y["chi"] - w["chi"]) / np.maximum(np.abs(w["chi"]), 1e-30)).max()))
+            elif field == "p01":
+                out = max(out, float(np.abs(y["p"] - w["p"])[:, :2].max()))
+            elif field == "p25":
+                out = max(out, float(np.abs(y["p"] - w["p"])[:, 2:].max()))
+            else:
+                out = max(out, float(np.count_nonzero(np.abs(y["iterations"] - w["iterations"]) > 1)))
+        return out
     far = np.count_nonzero(np.abs(g["iterations"] - w["iterations"]) > 1)
-    assert far <= max(1, len(g) // 200), f"{label}: iteration counts differ by > 1 on {far} sectors"
-    assert dp[:, :2].max() <= 5e-3, f"{label}: p0/p1 off by {dp[:, :2].max()}"
-    assert dp[:, 2:].max() <= 5e-5, f"{label}: p2..p5 off by {dp[:, 2:].max()}"
-    assert chi_rel.max() <= 5e-3, f"{label}: chi rel {chi_rel.max()}"
+    assert far <= max(1, len(g) // 200, 3 * yard("it")), f"{label}: iteration counts differ by > 1 on {far} sectors"
+    assert dp[:, :2].max() <= max(5e-3, 3 * yard("p01")), f"{label}: p0/p1 off by {dp[:, :2].max()}"
+    assert dp[:, 2:].max() <= max(5e-5, 3 * yard("p25")), f"{label}: p2..p5 off by {dp[:, 2:].max()}"
+    assert chi_rel.max() <= max(5e-3, 3 * yard("chi")), f"{label}: chi rel {chi_rel.max()}"
     f_gpu, f_self, f_exact = _strict_ok(g, w).mean(), _strict_ok(s8, w).mean(), _strict_ok(ex, w).mean()
     slack = 0.03 + 1.5 / np.sqrt(len(g))
     print(f"{label}: strict tolerance met on {100 * f_gpu:.1f} % of {len(g)} sectors "
@@ -255,12 +270,24 @@ def test_damped_solve(oracle):
             assert np.abs(got - ref).max() <= tol, (n, got, ref)
             assert np.abs(want - ref).max() <= tol, (n, want, ref)
             worst = max(worst, float(np.abs(got - want).max() / np.abs(ref).max()))
+            # the reference path (used on starved / ill-conditioned systems) is the oracle's
+            # pivoted QR operation by operation: same bits
+            got_qr = e.damped_solve(A, b, lam, s, reference_solver=True)
+            assert np.array_equal(got_qr, want), (n, got_qr, want)
     print(f"damped_solve: max |engine - oracle| / |dp| = {worst:.2e}")
     # semi-definite input: a textureless direction gets a zero step (like the QR's dropped pivot)
     A = np.diag([4.0, 0.0, 9.0]).astype(np.float32)
     got = e.damped_solve(A, np.array([8.0, 0.0, 18.0], np.float32), np.float32(0.0), np.float32(1.0))
     assert np.allclose(got, oracle.damped_solve(A, np.array([8.0, 0.0, 18.0], np.float32), 0.0, 1.0))
     assert np.allclose(got, [2.0, 0.0, 2.0])
+    # fewer samples than parameters: a rank-4 6x6 system, damped - the engine detects the
+    # small pivots and takes the reference path by itself
+    J = rng.standard_normal((4, 6)) * [3, 3, 20, 20, 20, 20]
+    A = (J.T @ J).astype(np.float32)
+    b = (J.T @ rng.standard_normal(4)).astype(np.float32)
+    for lam in (1e-4, 4e-5, 1e-9):
+        assert np.array_equal(e.damped_solve(A, b, np.float32(lam), np.float32(0.25)),
+                              oracle.damped_solve(A, b, np.float32(lam), np.float32(0.25)))
     e.close()
 
 
@@ -386,6 +413,40 @@ def test_annular_and_blob_sectors(oracle):
     # ground truth displacement at each sector centre (the images were deformed about (384,384))
     u_true = 0.9 + 0.001 * (got["und_cx"] - 384.0) + 0.0005 * (got["und_cy"] - 384.0)
     assert np.abs(got["p"][:, 0] - u_true).max() < 0.05
+    e.close()
+
+
+def test_starved_pyramid_level_is_bit_identical(oracle):
+    """BASELINE config 5's geometry in small: 17x17 sectors with a 4-level pyramid leave
+    2x2 .. 3x3 samples at level 3 for 6 parameters.  The damped system is singular, the
+    reference's pivoted QR decides the step and amplifies the last bit of A and b, so the
+    engine sums such levels in the reference's order and uses the reference's solver:
+    solving level 3 alone must reproduce the oracle BIT FOR BIT, and the full 4-level solve
+    must be as close to it as the reference is to itself."""
+    und, dfm = ca.speckle.speckle_pair(768, 768, p=(1.3, -0.7, 0.0005, 0.0, 0.0, -0.00025), seed=13)
+    xdim, ydim, cen = oracle.rect_sector_geometry(32.0, 32.0, 735.0, 735.0, 39, 39)
+    lists = [oracle.rect_points(cx - xdim, cy - ydim, cx + xdim, cy + ydim) for cx, cy in cen]
+    cen = cen.astype(np.float32)
+    # level 3 only
+    e = ca.HipCorrelationEngine(py_start=3, py_stop=3)
+    e.set_undeformed_image(und)
+    e.set_deformed_image(dfm)
+    e.set_rect_grid(32.0, 32.0, 735.0, 735.0, 39, 39)
+    e.commit_sectors()
+    assert e.sector_info(0)[0] == 289 and max(e.sector_level_count(s, 3) for s in range(0, 1521, 97)) <= 9
+    got = e.correlate_all(np.zeros(6, np.float32))
+    o = oracle.Oracle(py_start=3, py_stop=3)
+    o.set_image(0, und)
+    o.set_image(1, dfm)
+    want = o.correlate_sectors(lists, centers=cen)
+    assert got.tobytes() == want.tobytes()
+    e.close()
+    # all four levels
+    e, op = make_pair((und, dfm), ca.FM_UVUXUYVXVY, ca.IM_BICUBIC, oracle, py_stop=3)
+    e.set_rect_grid(32.0, 32.0, 735.0, 735.0, 39, 39)
+    e.commit_sectors()
+    got = e.correlate_all(np.zeros(6, np.float32))
+    compare_results(got, op.correlate_sectors(lists, centers=cen), "4-level, starved level 3")
     e.close()
 
 
