@@ -20,6 +20,15 @@ struct LkLevelView {
   int drows, dcols;    // def dims
 };
 
+// What the starved-level kernel (one lane per sector) leaves for the lane-group kernel.
+struct LkHandoff {
+  float p[6];        // parameters in the scale of `level_old`
+  int level;         // next pyramid level to solve; < py_start: the sector is finished
+  int level_old;     // level the parameters are scaled for
+  int reached;       // reached_iterations so far (correlation_class.cpp:452)
+  uint32_t n_evals, n_sample_evals, n_point_iters;
+};
+
 struct LkSolveArgs {
   const LkLevelView *lv; // [LK_MAX_LEVELS] in device memory
   const float2 *center;  // [S] level-0 centre of each sector
@@ -28,6 +37,7 @@ struct LkSolveArgs {
   float *last_p;         // [S][6] copy of the returned parameters (sequence state), may be null
   uint32_t *stats;       // [S][4]: evaluations, sample evaluations, point iterations, -
   const uint32_t *order; // optional [n_sectors] indirection (size classes), may be null
+  LkHandoff *handoff;    // [S] written by the starved-level kernel, read by the others (may be null)
   uint32_t *queue;       // next unclaimed slot of this launch (persistent mode), zeroed per launch
   int n_sectors;         // sectors in this launch
   int chunk;             // non-persistent: ceil(#workgroups / 8), XCD-contiguous chunk length

@@ -138,9 +138,11 @@ struct lk_engine {
   DevBuf<uint32_t> d_order;
   std::vector<uint32_t> h_order; // sectors grouped by size class
   int class_begin[kNumClasses + 1] = {0, 0, 0, 0, 0, 0};
-  bool class_safe[kNumClasses] = {false, false, false, false, false}; // a sector of the class has a starved level
+  bool class_starved[kNumClasses] = {false, false, false, false, false}; // a sector of the class has a starved level
+  bool force_safe = false; // LK_FORCE_SAFE: QR fallback for ill-conditioned systems in the lane-group kernels
   std::vector<int> h_class; // size class of every sector
   DevBuf<uint32_t> d_single, d_queue;
+  DevBuf<LkHandoff> d_handoff;
   DevBuf<float> d_scratch; // 64 floats for the stand-alone entry points
   DevBuf<float2> d_warp;
   bool stats_valid = false;
@@ -228,6 +230,7 @@ void lk_destroy(lk_engine *e) {
   e->d_order.release();
   e->d_single.release();
   e->d_queue.release();
+  e->d_handoff.release();
   e->d_scratch.release();
   e->d_warp.release();
   if (e->own_stream)
@@ -642,28 +645,26 @@ int lk_commit_sectors(lk_engine *e) {
         e->h_order.push_back((uint32_t)s);
   }
   e->class_begin[kNumClasses] = (int)e->h_order.size();
-  // starved levels (at most 2P samples for P parameters) need the reference-exact flavour
+  // Starved levels (at most 2P samples for P parameters; always the coarsest ones) are
+  // solved first by the one-lane-per-sector kernel, bit-identically to the reference.
   for (int c = 0; c < kNumClasses; ++c)
-    e->class_safe[c] = false;
-  if (const char *f = std::getenv("LK_FORCE_SAFE")) { // tuning / test hook
-    for (int c = 0; c < kNumClasses; ++c)
-      e->class_safe[c] = std::atoi(f) != 0;
-  } else {
-    for (int l : levels) {
-      if (l < cfg.py_start)
-        continue;
-      for (int s = 0; s < S; ++s) {
-        const int4 r = e->h_rect[l][(size_t)s];
-        const int n = r.z > 0 ? r.w : (int)(e->h_off[l][(size_t)s + 1] - e->h_off[l][(size_t)s]);
-        if (n <= 2 * e->P)
-          e->class_safe[e->h_class[(size_t)s]] = true;
-      }
+    e->class_starved[c] = false;
+  if (const char *f = std::getenv("LK_FORCE_SAFE")) // tuning / test hook
+    e->force_safe = std::atoi(f) != 0;
+  {
+    const int l = cfg.py_stop; // counts only shrink with the level: test the coarsest
+    for (int s = 0; s < S; ++s) {
+      const int4 r = e->h_rect[l][(size_t)s];
+      const int n = r.z > 0 ? r.w : (int)(e->h_off[l][(size_t)s + 1] - e->h_off[l][(size_t)s]);
+      if (n <= 2 * e->P)
+        e->class_starved[e->h_class[(size_t)s]] = true;
     }
   }
   HIPCHK(e->d_order.ensure((size_t)S));
   HIPCHK(hipMemcpy(e->d_order.p, e->h_order.data(), (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice));
   HIPCHK(e->d_single.ensure(1));
   HIPCHK(e->d_queue.ensure(8 * kNumClasses));
+  HIPCHK(e->d_handoff.ensure((size_t)S));
   HIPCHK(e->d_scratch.ensure(64));
   e->S = S;
   e->committed = true;
@@ -806,7 +807,11 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
     a.order = e->d_order.p + e->class_begin[c];
     a.n_sectors = n;
     a.queue = e->d_queue.p + 8 * c;
-    a.safe = e->class_safe[c] ? 1 : 0;
+    a.safe = e->force_safe ? 1 : 0;
+    if (e->class_starved[c]) { // coarsest level(s) first, one lane per sector
+      a.handoff = e->d_handoff.p;
+      HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, 1, e->stream));
+    }
     HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, kGroupOfClass[c], e->stream));
   }
   HIPCHK(hipEventRecord(e->ev_s1, e->stream));
@@ -871,8 +876,12 @@ int lk_correlate(lk_engine *e, int sector, float *guess_inout, lk_result *out) {
   const int group = kGroupOfClass[e->h_class[(size_t)sector]];
   a.n_sectors = 1;
   a.queue = e->d_queue.p;
-  a.safe = e->class_safe[e->h_class[(size_t)sector]] ? 1 : 0;
+  a.safe = e->force_safe ? 1 : 0;
   HIPCHK(hipEventRecord(e->ev_s0, e->stream));
+  if (e->class_starved[e->h_class[(size_t)sector]]) {
+    a.handoff = e->d_handoff.p;
+    HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, 1, e->stream));
+  }
   HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, group, e->stream));
   HIPCHK(hipEventRecord(e->ev_s1, e->stream));
   e->solve_timed = true;

@@ -260,7 +260,7 @@ __device__ __forceinline__ float rows_sum(float v) { // after row16_sum: add the
   return (r0 + r1) + (r2 + r3);
 }
 
-template <int MODEL, int INTERP, int GROUP, int THREADS, bool SAFE>
+template <int MODEL, int INTERP, int GROUP, int THREADS>
 __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
                                          Sums<n_params(MODEL)> &S, float *lds) {
   constexpr int P = n_params(MODEL);
@@ -270,23 +270,19 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
     S.v[i] = 0.f;
   bool bad = false;
   const int umaxr = c.urows - 1, umaxc = c.ucols - 1;
-  // Implicit rectangles are walked x-fastest so that neighbouring lanes read neighbouring
-  // pixels of one image row (a 16-lane group touches 1-2 cache lines per load instead of
-  // 16).  The reference enumerates y-fastest (manager_class.cpp:1607-1611); only the float
-  // summation order depends on that, and a parallel reduction does not keep it anyway.
-  //
-  // Starved levels (SAFE kernels only; at most 2P samples - fewer samples than parameters
-  // happen at the coarsest level of BASELINE config 5, 4-9 samples for 6 parameters) are
-  // the exception: there the 6x6
-  // system is (nearly) singular and the pivoted QR amplifies the last bit of A and b, so the
-  // sums themselves must be the reference's.  One sample per lane in the REFERENCE's
-  // order, then an ordered lane-by-lane sum (see below) gives bit-identical A, b, chi.
-  const bool tiny = SAFE && c.n <= 2 * P; // starved: at most twice as many samples as parameters
+  // Lane groups walk implicit rectangles x-fastest so that neighbouring lanes read
+  // neighbouring pixels of one image row (a 16-lane group touches 1-2 cache lines per load
+  // instead of 16).  The reference enumerates y-fastest (manager_class.cpp:1607-1611); only
+  // the float summation order depends on that, and a parallel reduction does not keep it
+  // anyway.  GROUP == 1 (one lane = one sector, the starved-level kernel) is different: the
+  // lane walks the samples in the REFERENCE's order and accumulates with a separate
+  // multiply and add, exactly like interpolation_class.cpp:722-749, so A, b and chi are
+  // bit-identical to the reference's.
   const float inv_w = c.rw > 0 ? 1.f / (float)c.rw : 0.f;
-  const int rh = c.rw > 0 ? c.n / c.rw : 1; // height of the implicit rectangle
+  const int rh = (GROUP == 1 && c.rw > 0) ? c.n / c.rw : 1; // height of the implicit rectangle
   for (int k = (int)threadIdx.x % GROUP; k < c.n; k += GROUP) {
     f32x2 q;
-    if (c.rw > 0 && tiny) { // reference order: x outer, y inner (manager_class.cpp:1607-1611)
+    if (GROUP == 1 && c.rw > 0) { // reference order: x outer, y inner
       const int col = k / rh;
       q.x = (float)(c.rx + col);
       q.y = (float)(c.ry + (k - col * rh));
@@ -320,52 +316,47 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
     float H[P];
     Warp<MODEL>::jac(Wx, Wy, dx, dy, H);
     int idx = 0;
+    if constexpr (GROUP == 1) { // rounded product, then rounded add (no FMA: contraction is off)
+      S.v[SumsT::N - 1] += V * V;
 #pragma unroll
-    for (int p1 = 0; p1 < P; ++p1)
+      for (int p1 = 0; p1 < P; ++p1) {
+        S.v[SumsT::NA + p1] += H[p1] * V;
 #pragma unroll
-      for (int p2 = p1; p2 < P; ++p2)
-        S.v[idx] = __builtin_fmaf(H[p1], H[p2], S.v[idx]), ++idx;
+        for (int p2 = p1; p2 < P; ++p2)
+          S.v[idx] += H[p1] * H[p2], ++idx;
+      }
+    } else {
 #pragma unroll
-    for (int p1 = 0; p1 < P; ++p1)
-      S.v[SumsT::NA + p1] = __builtin_fmaf(H[p1], V, S.v[SumsT::NA + p1]);
-    S.v[SumsT::N - 1] = __builtin_fmaf(V, V, S.v[SumsT::N - 1]);
+      for (int p1 = 0; p1 < P; ++p1)
+#pragma unroll
+        for (int p2 = p1; p2 < P; ++p2)
+          S.v[idx] = __builtin_fmaf(H[p1], H[p2], S.v[idx]), ++idx;
+#pragma unroll
+      for (int p1 = 0; p1 < P; ++p1)
+        S.v[SumsT::NA + p1] = __builtin_fmaf(H[p1], V, S.v[SumsT::NA + p1]);
+      S.v[SumsT::N - 1] = __builtin_fmaf(V, V, S.v[SumsT::N - 1]);
+    }
   }
+  if constexpr (GROUP == 1)
+    return bad; // nothing to reduce: the lane owns the whole sector
   // reconverged: all 64 lanes of every wave are active from here on
   const unsigned long long badmask = __ballot(bad);
-  if (tiny) {
-    // each of the group's first n lanes holds the rounded products of ONE sample (fma(a,b,0)
-    // rounds once, like the reference's multiply); add them in sample order, as
-    // interpolation_class.cpp:722-749 does
-    const int base = ((int)threadIdx.x & 63) & ~(GROUP < kWave ? GROUP - 1 : kWave - 1);
 #pragma unroll
-    for (int i = 0; i < SumsT::N; ++i) {
-      float acc = 0.f;
-      for (int l = 0; l < c.n; ++l)
-        acc += __shfl(S.v[i], base + l, 64);
-      S.v[i] = acc;
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < SumsT::N; ++i)
-      S.v[i] = row16_sum(S.v[i]);
-  }
+  for (int i = 0; i < SumsT::N; ++i)
+    S.v[i] = row16_sum(S.v[i]);
   if constexpr (GROUP == 16) {
     const int row = ((int)threadIdx.x & 63) >> 4;
     return ((badmask >> (16 * row)) & 0xffffull) != 0ull;
   } else if constexpr (GROUP == 32) { // two sectors per wavefront: add the partner row
-    if (!tiny) {
 #pragma unroll
-      for (int i = 0; i < SumsT::N; ++i)
-        S.v[i] += __shfl_xor(S.v[i], 16, 64);
-    }
+    for (int i = 0; i < SumsT::N; ++i)
+      S.v[i] += __shfl_xor(S.v[i], 16, 64);
     const int half = ((int)threadIdx.x & 63) >> 5;
     return ((badmask >> (32 * half)) & 0xffffffffull) != 0ull;
   } else {
-    if (!tiny) { // (the ordered sum above already left the total in every lane)
 #pragma unroll
-      for (int i = 0; i < SumsT::N; ++i)
-        S.v[i] = rows_sum(S.v[i]);
-    }
+    for (int i = 0; i < SumsT::N; ++i)
+      S.v[i] = rows_sum(S.v[i]);
     bool any_bad = badmask != 0ull;
     if constexpr (GROUP > kWave) {
       constexpr int WAVES = THREADS / kWave;
@@ -756,7 +747,8 @@ template <int MODEL, int INTERP, int GROUP, int THREADS, bool SAFE>
 __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) lk_solve_kernel(LkSolveArgs a) {
   constexpr int P = n_params(MODEL);
   using SumsT = Sums<P>;
-  constexpr bool COLD_IN_LDS = GROUP <= kWave;
+  constexpr bool COLD_IN_LDS = GROUP > 1 && GROUP <= kWave;
+  constexpr bool STARVED = GROUP == 1; // one lane per sector: solves only the starved top levels
   constexpr int RED_WORDS = GROUP > kWave ? (THREADS / kWave) * (SumsT::N + 1) + 1 : 1;
   __shared__ float lds[RED_WORDS];
   __shared__ uint32_t cold_lds[COLD_IN_LDS ? (THREADS / GROUP) * kColdWords : 1];
@@ -772,6 +764,27 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
   int phase = PH_FETCH;
   LevelCtx c{};
   SumsT S;
+
+  auto level_count = [&](int level, int sector) -> int { // samples of a sector at a level
+    const LkLevelView lv = a.lv[level];
+    const int4 rc = lv.rect[sector];
+    return rc.z > 0 ? rc.w : (int)(lv.off[sector + 1] - lv.off[sector]);
+  };
+
+  auto hand_over = [&](const Cold &k) { // STARVED kernel: leave the rest to the lane groups
+    LkHandoff h;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      h.p[i] = i < P ? p[i] : 0.f;
+    h.level = k.level;
+    h.level_old = k.level_old;
+    h.reached = k.reached;
+    h.n_evals = k.n_evals;
+    h.n_sample_evals = k.n_sample_evals;
+    h.n_point_iters = k.n_point_iters;
+    a.handoff[k.s] = h;
+    phase = PH_FETCH;
+  };
 
   auto enter_level = [&](Cold &k) { // top of the level loop (:373-408)
     const LkLevelView lv = a.lv[k.level];
@@ -827,6 +840,11 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
         a.stats[(size_t)k.s * 4 + 2] = k.n_point_iters;
         a.stats[(size_t)k.s * 4 + 3] = 0;
       }
+      if (STARVED) {
+        LkHandoff h{};
+        h.level = a.py_start - 1; // finished
+        a.handoff[k.s] = h;
+      }
     }
     phase = PH_FETCH;
   };
@@ -854,17 +872,36 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
       if (slot < a.n_sectors) {
         Cold k{};
         k.s = a.order ? (int)a.order[slot] : slot;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-          p[i] = i < P ? a.guess[(size_t)k.s * 6 + i] : 0.f;
         const float2 c0 = a.center[k.s];
         k.c0x = c0.x;
         k.c0y = c0.y;
-        k.level = a.py_stop;
-        k.level_old = 0;
         k.use_saved = 1;
-        enter_level(k);
-        cold.store(cold_slot, k);
+        if (!STARVED && a.handoff) { // continue where the starved-level kernel stopped
+          const LkHandoff h = a.handoff[k.s];
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+            p[i] = i < P ? h.p[i] : 0.f;
+          k.level = h.level;
+          k.level_old = h.level_old;
+          k.reached = h.reached;
+          k.n_evals = h.n_evals;
+          k.n_sample_evals = h.n_sample_evals;
+          k.n_point_iters = h.n_point_iters;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+            p[i] = i < P ? a.guess[(size_t)k.s * 6 + i] : 0.f;
+          k.level = a.py_stop;
+          k.level_old = 0;
+        }
+        if (k.level < a.py_start) {
+          // finished by the starved-level kernel (result already written): take another
+        } else if (STARVED && level_count(k.level, k.s) > 2 * P) {
+          hand_over(k); // nothing starved here: the lane-group kernel does it all
+        } else {
+          enter_level(k);
+          cold.store(cold_slot, k);
+        }
       } else {
         phase = PH_EXIT;
       }
@@ -880,12 +917,12 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
     LevelCtx ce = c;
     if (!active)
       ce.n = 0;
-    const bool err = evaluate<MODEL, INTERP, GROUP, THREADS, SAFE>(ce, p, S, lds);
+    const bool err = evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds);
     if (active) {
       Cold k = cold.load(cold_slot);
       ++k.n_evals;
       k.n_sample_evals += (uint32_t)c.n;
-      bool level_end = false, iter_start = false, finished = false;
+      bool level_end = false, iter_start = false, finished = false, handed = false;
       if (err) { // :413-419 (evaluation #0: return at once), :484-489, :511-516 (break)
         k.error = LK_ERROR_INTERPOLATION_OUT_OF_IMAGE;
         if (phase == PH_EVAL0) {
@@ -902,7 +939,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
 #pragma unroll
         for (int i = 0; i < P; ++i)
           tent[i] = p[i];
-        damped_step<P, SAFE>(S, lam_use, c.scaling, p, c.n <= 2 * P); // p += dp (compute_model_parameters)
+        damped_step<P, SAFE || STARVED>(S, lam_use, c.scaling, p, STARVED); // p += dp (compute_model_parameters)
         if (phase == PH_EVAL0) {
           ++k.n_point_iters;
           k.lg_chi = chi;
@@ -956,12 +993,16 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
         if (k.level < a.py_start) {
           translate<P>(p, k.level_old, 0);
           finished = true;
+        } else if (STARVED && level_count(k.level, k.s) > 2 * P) {
+          handed = true;
         } else {
           enter_level(k);
         }
       }
       if (finished)
         finish_sector(k);
+      else if (handed)
+        hand_over(k);
       else
         cold.store(cold_slot, k);
     }
@@ -1000,7 +1041,7 @@ __global__ void __launch_bounds__(256) lk_eval_kernel(LkEvalArgs a) {
   for (int i = 0; i < 6; ++i)
     p[i] = a.p[i];
   SumsT S;
-  bool err = evaluate<MODEL, INTERP, GROUP, 256, true>(c, p, S, lds);
+  bool err = evaluate<MODEL, INTERP, GROUP, 256>(c, p, S, lds);
   if (threadIdx.x == 0) {
     for (int i = 0; i < 44; ++i)
       a.out[i] = 0.f;
@@ -1188,15 +1229,18 @@ static hipError_t launch_solve_gs(const LkSolveArgs &a, hipStream_t st) {
     return f ? atoi(f) : -1;
   }();
   b.persistent = force_persistent >= 0 ? force_persistent : (want > 2 * resident ? 1 : 0);
+  if (GROUP == 1)
+    b.persistent = 0; // every lane takes exactly one sector
   b.chunk = (want + 7) / 8;
   dim3 grid((unsigned)(b.persistent ? resident : 8 * b.chunk));
   hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, GROUP, THREADS, SAFE>), grid, dim3(THREADS), 0, st, b);
   return hipGetLastError();
 }
 
-// SAFE flavour: starved levels are summed in the reference's order and ill-conditioned
-// systems go through the reference's pivoted QR (launched when a sector has a level with
-// at most 2P samples, a.safe); the fast flavour carries neither.
+// SAFE flavour: ill-conditioned systems go through the reference's pivoted QR inside the
+// lane-group kernel too (LK_FORCE_SAFE=1; costs a wavefront of occupancy); the default fast
+// flavour zeroes the step of a parameter whose pivot is bad.  Starved levels never get here:
+// the GROUP == 1 kernel solves them first.
 template <int MODEL, int INTERP, int GROUP, int THREADS>
 static hipError_t launch_solve_g(const LkSolveArgs &a, hipStream_t st) {
   return a.safe ? launch_solve_gs<MODEL, INTERP, GROUP, THREADS, true>(a, st)
@@ -1206,6 +1250,7 @@ static hipError_t launch_solve_g(const LkSolveArgs &a, hipStream_t st) {
 template <int MODEL, int INTERP>
 static hipError_t launch_solve_mi(const LkSolveArgs &a, int group, hipStream_t st) {
   switch (group) {
+  case 1: return launch_solve_gs<MODEL, INTERP, 1, 64, false>(a, st); // starved levels, one lane per sector
   case 16: return launch_solve_g<MODEL, INTERP, 16, 64>(a, st);
   case 32: return launch_solve_g<MODEL, INTERP, 32, 64>(a, st);
   case 64: return launch_solve_g<MODEL, INTERP, 64, 64>(a, st);
