@@ -152,6 +152,14 @@ def main():
     if rank == 0:
         value = total_pit / dt_max
         achieved = st["algorithmic_bytes"] / (solve_avg_ms * 1e-3) / 1e9
+        # HBM bytes per solve launch from the PMC passes of this workload (FETCH_SIZE +
+        # WRITE_SIZE, calibrated; profiles/r01_pmc_traffic.txt) - a profile, not a live counter
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                traffic = json.load(f)["solve_kernel_hbm_bytes_per_launch_C2"] / (solve_avg_ms * 1e-3) / 1e9
+        except Exception:
+            pass
         line = {
             "metric": "correlation-point-iterations/sec",
             "value": value,
@@ -169,7 +177,7 @@ def main():
                        "interpolation": "bicubic", "parallelism": f"sectors sharded x{world}",
                        "step": "pyramid(und)+pyramid(def)+solve, inputs resident in HBM"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "lk_solve_kernel<fm_UVUxUyVxVy, im_bicubic> (persistent; 32-lane groups, 2 sectors per wavefront)",
                          "kernel_ms": solve_avg_ms,
                          "algorithmic_bytes_per_launch": st["algorithmic_bytes"]},
