@@ -9,9 +9,10 @@ One "step" = one pass of the hot path over one image pair whose level-0 pixels a
 resident in HBM: build both image pyramids (und, def), solve every sector of the ROI grid
 coarse-to-fine on the device, leave the 48-byte result records in HBM.
 N > 1 ("weak" scaling): one process per GPU; every step rank 0's deformed frame is
-broadcast over RCCL/xGMI, each rank correlates its own 10 000-sector grid (the C2 grid
-shifted by `rank` pixels - a denser measurement grid on the same pair) and the result
-records are all-gathered.  value = point-iterations of ALL ranks / max-over-ranks time.
+broadcast over RCCL/xGMI (double-buffered: frame k+1 travels while frame k is solved), each
+rank correlates its own 10 000-sector grid (the C2 grid shifted by `rank` pixels - a denser
+measurement grid on the same pair) and the result records are all-gathered (asynchronously,
+double-buffered).  value = point-iterations of ALL ranks / max-over-ranks time.
 
 Prints ONE JSON line (rank 0).
 """
@@ -104,20 +105,38 @@ def main():
     S = e.n_sectors
     n0 = e.sector_info(0)[0]
     d_guess = torch.zeros((S, 6), dtype=torch.float32, device=dev)
-    d_res = torch.empty((S, 48), dtype=torch.uint8, device=dev)
-    d_all = torch.empty((world * S, 48), dtype=torch.uint8, device=dev) if use_dist else None
+    # double buffers: the broadcast of frame k+1 and the gather of the records of frame k
+    # run on RCCL's streams while frame k / k+1 is being solved (the reference prefetches the
+    # next frame the same way, manager_class.cpp:1438-1447)
+    d_defs = [d_def, d_def.clone()]
+    d_ress = [torch.empty((S, 48), dtype=torch.uint8, device=dev) for _ in range(2)]
+    d_alls = [torch.empty((world * S, 48), dtype=torch.uint8, device=dev) for _ in range(2)] if use_dist else None
+    pending = {"bcast": None, "gather": [None, None], "k": 0}
+
+    def prefetch(k):  # frame k -> d_defs[k % 2], over RCCL / xGMI
+        return dist.broadcast(d_defs[k % 2], src=0, async_op=True) if use_dist else None
+
+    pending["bcast"] = prefetch(0)
 
     def step():
+        k = pending["k"]
         if use_dist:
-            dist.broadcast(d_def, src=0)                       # new frame over RCCL / xGMI
-        e.set_image_device(ca.IMG_UND, d_und.data_ptr(), wl.size, wl.size)   # pyramid build (und)
-        e.set_image_device(ca.IMG_DEF, d_def.data_ptr(), wl.size, wl.size)   # pyramid build (def)
-        e.correlate_all_device(d_guess.data_ptr(), d_res.data_ptr())         # the solve
-        if use_dist:
-            dist.all_gather_into_tensor(d_all, d_res)          # gather of warp parameters
+            pending["bcast"].wait()                      # frame k has arrived
+            pending["bcast"] = prefetch(k + 1)           # frame k+1 travels during this solve
+            if pending["gather"][k % 2] is not None:
+                pending["gather"][k % 2].wait()          # records of frame k-2 have left d_ress[k % 2]
+        e.set_image_device(ca.IMG_UND, d_und.data_ptr(), wl.size, wl.size)            # pyramid build (und)
+        e.set_image_device(ca.IMG_DEF, d_defs[k % 2].data_ptr(), wl.size, wl.size)    # pyramid build (def)
+        e.correlate_all_device(d_guess.data_ptr(), d_ress[k % 2].data_ptr())          # the solve
+        if use_dist:                                     # gather of warp parameters
+            pending["gather"][k % 2] = dist.all_gather_into_tensor(d_alls[k % 2], d_ress[k % 2], async_op=True)
+        pending["k"] = k + 1
 
     def fence():
         if use_dist:
+            for w in pending["gather"]:
+                if w is not None:
+                    w.wait()
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -135,7 +154,7 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
     for _ in range(args.steps):
-        e.correlate_all_device(d_guess.data_ptr(), d_res.data_ptr())
+        e.correlate_all_device(d_guess.data_ptr(), d_ress[0].data_ptr())
     e1.record(stream)
     torch.cuda.synchronize(dev)
     solve_avg_ms = e0.elapsed_time(e1) / args.steps
@@ -148,7 +167,7 @@ def main():
     dt_max = float(tmax.item())
     total_pit = float(pit.item()) * args.steps
 
-    res = d_res.cpu().numpy().view(ca.RESULT_DTYPE).reshape(-1)
+    res = d_ress[0].cpu().numpy().view(ca.RESULT_DTYPE).reshape(-1)
     if rank == 0:
         value = total_pit / dt_max
         achieved = st["algorithmic_bytes"] / (solve_avg_ms * 1e-3) / 1e9

@@ -1105,17 +1105,34 @@ __global__ void __launch_bounds__(256) lk_pyramid_kernel(const uint8_t *__restri
   const float km[5] = {0.05f, 0.25f, 0.4f, 0.25f, 0.05f};
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   const bool row_inside = tj >= 1 && tj < trows - 1;
+  // interior threads fetch their 11-byte window as four (unaligned) dwords per source row
+  const bool fast = 2 * ti0 - 4 >= 0 && 2 * ti0 + 12 <= scols;
   if (row_inside) {
 #pragma unroll
     for (int dj = -2; dj <= 2; ++dj) {
-      const uint8_t *row = src + (size_t)(2 * tj + dj) * (size_t)scols;
-      // source columns 2*ti0-2 .. 2*ti0+8 (11 bytes), clamped loads for the border threads
-      float px[11];
+      gptr<uint8_t> row = (gptr<uint8_t>)src + (size_t)(2 * tj + dj) * (size_t)scols;
+      float px[11]; // source columns 2*ti0-2 .. 2*ti0+8
+      if (fast) {
+        const uint32_t w0 = load_u32_unaligned(row + 2 * ti0 - 4), w1 = load_u32_unaligned(row + 2 * ti0);
+        const uint32_t w2 = load_u32_unaligned(row + 2 * ti0 + 4), w3 = load_u32_unaligned(row + 2 * ti0 + 8);
+        px[0] = ub2(w0);
+        px[1] = ub3(w0);
+        px[2] = ub0(w1);
+        px[3] = ub1(w1);
+        px[4] = ub2(w1);
+        px[5] = ub3(w1);
+        px[6] = ub0(w2);
+        px[7] = ub1(w2);
+        px[8] = ub2(w2);
+        px[9] = ub3(w2);
+        px[10] = ub0(w3);
+      } else { // border threads: clamped byte loads (their border outputs are zeroed below)
 #pragma unroll
-      for (int c = 0; c < 11; ++c) {
-        int sc = 2 * ti0 - 2 + c;
-        sc = min(max(sc, 0), scols - 1);
-        px[c] = (float)row[sc];
+        for (int c = 0; c < 11; ++c) {
+          int sc = 2 * ti0 - 2 + c;
+          sc = min(max(sc, 0), scols - 1);
+          px[c] = (float)row[sc];
+        }
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -1124,13 +1141,21 @@ __global__ void __launch_bounds__(256) lk_pyramid_kernel(const uint8_t *__restri
           acc[t] += px[2 * t + di] * (km[di] * km[dj + 2]);
     }
   }
+  uint8_t o[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    int ti = ti0 + t;
-    if (ti < tcols) {
-      bool inside = row_inside && ti >= 1 && ti < tcols - 1;
-      dst[(size_t)tj * (size_t)tcols + (size_t)ti] = inside ? (uint8_t)acc[t] : (uint8_t)0;
-    }
+    const int ti = ti0 + t;
+    const bool inside = row_inside && ti >= 1 && ti < tcols - 1;
+    o[t] = inside ? (uint8_t)acc[t] : (uint8_t)0;
+  }
+  uint8_t *out = dst + (size_t)tj * (size_t)tcols + (size_t)ti0;
+  if (ti0 + 4 <= tcols && (tcols & 3) == 0) { // aligned row pitch: one dword store
+    *reinterpret_cast<uint32_t *>(out) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (ti0 + t < tcols)
+        out[t] = o[t];
   }
 }
 
