@@ -535,3 +535,35 @@ def test_config2_full_size_properties(oracle):
     compare_results(r1[pick], want, "config 2 subset")
     assert (r1[pick]["iterations"] == want[0]["iterations"]).mean() >= 0.95
     e.close()
+
+
+def test_mixed_size_classes_in_one_engine(oracle, speckle512):
+    """Small rectangles, a mid-size explicit list and a large rectangle in ONE engine: every
+    size class (16 / 32 / 64 lanes, 4- and 8-wavefront workgroups) gets its own launch through
+    the `order` indirection, and records land at their sector index."""
+    e, o = make_pair(speckle512, ca.FM_UVUXUYVXVY, ca.IM_BICUBIC, oracle)
+    lists, cens = [], []
+
+    def rect(s, x0, y0, x1, y1):
+        e.resetPolygon_rect(s, x0, y0, x1, y1)
+        lists.append(oracle.rect_points(x0, y0, x1, y1))
+        cens.append(((x0 + x1) * 0.5, (y0 + y1) * 0.5))
+
+    rect(0, 100, 100, 118, 118)            # 361 samples
+    rect(1, 150, 100, 220, 170)            # 5041
+    rect(2, 130, 260, 148, 278)            # 361
+    rect(3, 200, 200, 420, 420)            # 48841
+    xy = oracle.rect_points(60, 300, 100, 330)[::2].copy()   # every other sample: explicit list, 636
+    e.set_sector_points(4, xy, center=(80.0, 315.0))
+    lists.append(xy)
+    cens.append((80.0, 315.0))
+    rect(5, 300, 60, 330, 95)              # 1116
+    e.commit_sectors()
+    got = e.correlate_all(np.zeros(6, np.float32))
+    want = o.correlate_sectors(lists, centers=np.array(cens, np.float32))
+    assert list(got["n_points"]) == [361, 5041, 361, 48841, 636, 1116]
+    compare_results(got, want, "mixed classes")
+    for s in (1, 3, 4):
+        one, _ = e.correlate(s, np.zeros(6, np.float32))
+        assert one.tobytes() == got[s].tobytes()
+    e.close()
