@@ -37,6 +37,10 @@ struct LkSolveArgs {
   float *last_p;         // [S][6] copy of the returned parameters (sequence state), may be null
   uint32_t *stats;       // [S][4]: evaluations, sample evaluations, point iterations, -
   const uint32_t *order; // optional [n_sectors] indirection (size classes), may be null
+  // teams: a giant sector is shared by team_w workgroups of the 512-thread kernel (0/1: off)
+  int team_w;
+  float *team_partials;  // [n_sectors][2][team_w][32]: per-workgroup sums, double-buffered by step parity
+  uint32_t *team_arrivals; // [n_sectors]: monotonic arrival counter (zeroed per launch)
   LkHandoff *handoff;    // [S] written by the starved-level kernel, read by the others (may be null)
   uint32_t *queue;       // next unclaimed slot of this launch (persistent mode), zeroed per launch
   int n_sectors;         // sectors in this launch

@@ -101,11 +101,15 @@ template <class T> struct DevBuf {
 } // namespace
 
 // lanes that own one sector: a 16-lane DPP row (4 sectors per wavefront), one wavefront,
-// or a workgroup of 4 / 8 wavefronts
-static const int kNumClasses = 5;
-static const int kGroupOfClass[kNumClasses] = {16, 32, 64, 256, 512};
+// a workgroup of 4 / 8 wavefronts, or - for giant sectors (a blob over most of the image) -
+// a team of up to kMaxTeam 8-wavefront workgroups
+static const int kNumClasses = 6;
+static const int kTeamClass = 5;
+static const int kGroupOfClass[kNumClasses] = {16, 32, 64, 256, 512, 512};
+static const int kTeamSamples = 32768; // level-0 samples per workgroup of a team (64 per lane)
+static const int kMaxTeam = 128;
 static int size_class(int n0) {
-  return n0 <= 512 ? 0 : (n0 <= 2048 ? 1 : (n0 <= 8192 ? 2 : (n0 <= 65536 ? 3 : 4)));
+  return n0 <= 512 ? 0 : (n0 <= 2048 ? 1 : (n0 <= 8192 ? 2 : (n0 <= 65536 ? 3 : (n0 <= 8 * kTeamSamples ? 4 : 5))));
 }
 
 struct lk_engine {
@@ -137,12 +141,15 @@ struct lk_engine {
   DevBuf<uint32_t> d_stats;
   DevBuf<uint32_t> d_order;
   std::vector<uint32_t> h_order; // sectors grouped by size class
-  int class_begin[kNumClasses + 1] = {0, 0, 0, 0, 0, 0};
-  bool class_starved[kNumClasses] = {false, false, false, false, false}; // a sector of the class has a starved level
+  int class_begin[kNumClasses + 1] = {0, 0, 0, 0, 0, 0, 0};
+  bool class_starved[kNumClasses] = {false, false, false, false, false, false}; // a sector of the class has a starved level
   bool force_safe = false; // LK_FORCE_SAFE: QR fallback for ill-conditioned systems in the lane-group kernels
   std::vector<int> h_class; // size class of every sector
   DevBuf<uint32_t> d_single, d_queue;
   DevBuf<LkHandoff> d_handoff;
+  int team_w = 0; // workgroups per sector of the team class
+  DevBuf<float> d_team_partials;
+  DevBuf<uint32_t> d_team_arrivals;
   DevBuf<float> d_scratch; // 64 floats for the stand-alone entry points
   DevBuf<float2> d_warp;
   bool stats_valid = false;
@@ -605,14 +612,14 @@ int lk_commit_sectors(lk_engine *e) {
   // size classes -> lanes per sector.  A class whose sectors are too few to fill the chip
   // (< 2048 wavefronts) and still large per lane is promoted to the next wider group.
   e->h_class.assign((size_t)S, 0);
-  size_t cnt[kNumClasses] = {0, 0, 0, 0, 0}, tot[kNumClasses] = {0, 0, 0, 0, 0};
+  size_t cnt[kNumClasses] = {0, 0, 0, 0, 0, 0}, tot[kNumClasses] = {0, 0, 0, 0, 0, 0};
   for (int s = 0; s < S; ++s) {
     int n0 = e->hs[(size_t)s].n0(), c = size_class(n0);
     e->h_class[(size_t)s] = c;
     cnt[c]++;
     tot[c] += (size_t)n0;
   }
-  for (int c = 0; c + 1 < kNumClasses; ++c) {
+  for (int c = 0; c + 1 < kTeamClass; ++c) { // (nothing is promoted into the team class)
     if (!cnt[c])
       continue;
     // Wavefronts are dealt to SIMD slots as earlier ones retire; that only balances the
@@ -635,6 +642,27 @@ int lk_commit_sectors(lk_engine *e) {
     for (int c = 0; c < kNumClasses; ++c)
       if (kGroupOfClass[c] == g)
         std::fill(e->h_class.begin(), e->h_class.end(), c);
+  }
+  int force_team = 0;
+  if (const char *f = std::getenv("LK_FORCE_TEAM")) { // test hook: every sector gets a team of this width
+    force_team = std::atoi(f);
+    if (force_team > 1)
+      std::fill(e->h_class.begin(), e->h_class.end(), kTeamClass);
+  }
+  e->team_w = 0;
+  {
+    int n_team = 0, n0_max = 0;
+    for (int s = 0; s < S; ++s)
+      if (e->h_class[(size_t)s] == kTeamClass) {
+        ++n_team;
+        n0_max = std::max(n0_max, e->hs[(size_t)s].n0());
+      }
+    if (n_team) {
+      int w = force_team > 1 ? force_team : (n0_max + kTeamSamples - 1) / kTeamSamples;
+      e->team_w = std::min(std::max(w, 2), kMaxTeam); // the launch clamps it to what is resident
+      HIPCHK(e->d_team_partials.ensure((size_t)n_team * 2 * (size_t)e->team_w * 32));
+      HIPCHK(e->d_team_arrivals.ensure((size_t)n_team));
+    }
   }
   e->h_order.clear();
   e->h_order.reserve((size_t)S);
@@ -808,6 +836,11 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
     a.n_sectors = n;
     a.queue = e->d_queue.p + 8 * c;
     a.safe = e->force_safe ? 1 : 0;
+    if (c == kTeamClass) {
+      a.team_w = e->team_w;
+      a.team_partials = e->d_team_partials.p;
+      a.team_arrivals = e->d_team_arrivals.p;
+    }
     if (e->class_starved[c]) { // coarsest level(s) first, one lane per sector
       a.handoff = e->d_handoff.p;
       HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, 1, e->stream));
@@ -877,6 +910,11 @@ int lk_correlate(lk_engine *e, int sector, float *guess_inout, lk_result *out) {
   a.n_sectors = 1;
   a.queue = e->d_queue.p;
   a.safe = e->force_safe ? 1 : 0;
+  if (e->h_class[(size_t)sector] == kTeamClass) {
+    a.team_w = e->team_w;
+    a.team_partials = e->d_team_partials.p;
+    a.team_arrivals = e->d_team_arrivals.p;
+  }
   HIPCHK(hipEventRecord(e->ev_s0, e->stream));
   if (e->class_starved[e->h_class[(size_t)sector]]) {
     a.handoff = e->d_handoff.p;

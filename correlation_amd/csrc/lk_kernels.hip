@@ -260,11 +260,30 @@ __device__ __forceinline__ float rows_sum(float v) { // after row16_sum: add the
   return (r0 + r1) + (r2 + r3);
 }
 
+// A "team": several 512-thread workgroups share ONE giant sector (millions of samples).
+// Every workgroup runs the identical state machine on identical totals, so the only
+// exchange is one all-to-all of the 28 sums per evaluation through global memory:
+// plain stores of the workgroup's sums -> every wave's vmcnt(0) -> workgroup barrier ->
+// agent-scope release -> arrival counter; then one lane polls the counter (relaxed,
+// s_sleep, bounded), agent-scope acquire, workgroup barrier, and 29 lanes add up the
+// team's partial sums in a fixed order (deterministic).  Buffers alternate with the step
+// parity; a workgroup cannot be two steps ahead of its team.  All workgroups of a launch
+// are resident (the host caps the grid), so the wait always ends; the spin is bounded anyway.
+struct TeamCtx {
+  int w = 1, rank = 0, slot = 0;
+  uint32_t step = 0;
+  float *partials = nullptr;
+  uint32_t *arrivals = nullptr;
+  bool timed_out = false;
+};
+
 template <int MODEL, int INTERP, int GROUP, int THREADS>
 __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
-                                         Sums<n_params(MODEL)> &S, float *lds) {
+                                         Sums<n_params(MODEL)> &S, float *lds, TeamCtx *team = nullptr) {
   constexpr int P = n_params(MODEL);
   using SumsT = Sums<P>;
+  const int team_w = (GROUP == 512 && team) ? team->w : 1;
+  const int team_rank = (GROUP == 512 && team) ? team->rank : 0;
 #pragma unroll
   for (int i = 0; i < SumsT::N; ++i)
     S.v[i] = 0.f;
@@ -280,7 +299,7 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
   // bit-identical to the reference's.
   const float inv_w = c.rw > 0 ? 1.f / (float)c.rw : 0.f;
   const int rh = (GROUP == 1 && c.rw > 0) ? c.n / c.rw : 1; // height of the implicit rectangle
-  for (int k = (int)threadIdx.x % GROUP; k < c.n; k += GROUP) {
+  for (int k = team_rank * GROUP + (int)threadIdx.x % GROUP; k < c.n; k += GROUP * team_w) {
     f32x2 q;
     if (GROUP == 1 && c.rw > 0) { // reference order: x outer, y inner
       const int col = k / rh;
@@ -381,6 +400,51 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
       for (int w = 0; w < WAVES; ++w)
         eb += lds[w * STRIDE + SumsT::N];
       any_bad = eb != 0.f;
+      if constexpr (GROUP == 512) {
+        if (team_w > 1) { // all-to-all of the workgroup totals inside the team
+          ++team->step;
+          float *mine = team->partials + (((size_t)team->slot * 2 + (team->step & 1u)) * (size_t)team_w) * 32;
+          __syncthreads(); // everybody has its totals out of lds
+          if (threadIdx.x == 0) {
+#pragma unroll
+            for (int i = 0; i < SumsT::N; ++i)
+              mine[(size_t)team_rank * 32 + i] = S.v[i];
+            mine[(size_t)team_rank * 32 + SumsT::N] = any_bad ? 1.f : 0.f;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(team->arrivals + team->slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t target = team->step * (uint32_t)team_w;
+            bool ok = false;
+            // normally a few microseconds; ~1 s bound, and no second wait once the team is broken
+            for (int spin = 0; spin < (team->timed_out ? 0 : (1 << 20)); ++spin) {
+              if (__hip_atomic_load(team->arrivals + team->slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) {
+                ok = true;
+                break;
+              }
+              __builtin_amdgcn_s_sleep(8);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds[0] = ok ? 0.f : 1.f;
+          }
+          __syncthreads();
+          const bool timeout = lds[0] != 0.f;
+          __syncthreads();
+          if ((int)threadIdx.x <= SumsT::N) { // one lane per value: fixed summation order
+            float t = 0.f;
+            for (int w = 0; w < team_w; ++w)
+              t += mine[(size_t)w * 32 + threadIdx.x];
+            lds[threadIdx.x] = t;
+          }
+          __syncthreads();
+#pragma unroll
+          for (int i = 0; i < SumsT::N; ++i)
+            S.v[i] = lds[i];
+          any_bad = lds[SumsT::N] != 0.f;
+          team->timed_out = team->timed_out || timeout;
+        }
+      }
     }
     return any_bad;
   }
@@ -766,6 +830,16 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
   int phase = PH_FETCH;
   LevelCtx c{};
   SumsT S;
+  TeamCtx team;
+  if constexpr (GROUP == 512) {
+    if (a.team_w > 1) {
+      team.w = a.team_w;
+      team.rank = (int)blockIdx.x % a.team_w;
+      team.slot = (int)blockIdx.x / a.team_w;
+      team.partials = a.team_partials;
+      team.arrivals = a.team_arrivals;
+    }
+  }
 
   auto level_count = [&](int level, int sector) -> int { // samples of a sector at a level
     const LkLevelView lv = a.lv[level];
@@ -818,7 +892,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
   };
 
   auto finish_sector = [&](const Cold &k) { // results of Newton_Raphson (:638-639, :848-870)
-    if ((int)threadIdx.x % GROUP == 0) {
+    if ((int)threadIdx.x % GROUP == 0 && team.rank == 0) {
       lk_result r;
 #pragma unroll
       for (int i = 0; i < 6; ++i)
@@ -827,7 +901,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
       const int4 rc0 = a.lv[0].rect[k.s];
       r.numberOfPoints = rc0.z > 0 ? rc0.w : (int)(a.lv[0].off[k.s + 1] - a.lv[0].off[k.s]);
       r.iterations = k.reached;
-      r.errorCode = k.error;
+      r.errorCode = team.timed_out ? (int)LK_ERROR_DEVICE : k.error;
       r.undCenterX = k.c0x;
       r.undCenterY = k.c0y;
       a.result[k.s] = r;
@@ -859,6 +933,8 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
         // of sectors (neighbouring sectors share image rows in its L2)
         const int wg_slot = ((int)blockIdx.x & 7) * a.chunk + ((int)blockIdx.x >> 3);
         slot = first_fetch ? wg_slot * (THREADS / GROUP) + (int)threadIdx.x / GROUP : a.n_sectors;
+        if (GROUP == 512 && team.w > 1) // a team's workgroups all take the team's sector
+          slot = first_fetch ? team.slot : a.n_sectors;
         first_fetch = false;
       } else if constexpr (GROUP > kWave) {
         __syncthreads(); // everybody is done reading lds from the last evaluation
@@ -919,7 +995,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
     LevelCtx ce = c;
     if (!active)
       ce.n = 0;
-    const bool err = evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds);
+    const bool err = evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds, &team);
     if (active) {
       Cold k = cold.load(cold_slot);
       ++k.n_evals;
@@ -1258,6 +1334,21 @@ static hipError_t launch_solve_gs(const LkSolveArgs &a, hipStream_t st) {
   b.persistent = force_persistent >= 0 ? force_persistent : (want > 2 * resident ? 1 : 0);
   if (GROUP == 1)
     b.persistent = 0; // every lane takes exactly one sector
+  if (GROUP == 512 && a.team_w > 1) {
+    // teams wait on each other: every workgroup of the launch must be resident at once
+    b.team_w = a.team_w < resident / a.n_sectors ? a.team_w : resident / a.n_sectors;
+    if (b.team_w > 1) {
+      hipError_t te = hipMemsetAsync(a.team_arrivals, 0, (size_t)a.n_sectors * sizeof(uint32_t), st);
+      if (te != hipSuccess)
+        return te;
+      b.persistent = 0;
+      b.chunk = 0;
+      hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, GROUP, THREADS, SAFE>),
+                         dim3((unsigned)(a.n_sectors * b.team_w)), dim3(THREADS), 0, st, b);
+      return hipGetLastError();
+    }
+  }
+  b.team_w = 0;
   b.chunk = (want + 7) / 8;
   dim3 grid((unsigned)(b.persistent ? resident : 8 * b.chunk));
   hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, GROUP, THREADS, SAFE>), grid, dim3(THREADS), 0, st, b);

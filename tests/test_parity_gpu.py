@@ -567,3 +567,37 @@ def test_mixed_size_classes_in_one_engine(oracle, speckle512):
         one, _ = e.correlate(s, np.zeros(6, np.float32))
         assert one.tobytes() == got[s].tobytes()
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("width", [2, 5])
+def test_team_of_workgroups_per_sector(oracle, speckle512, width, monkeypatch):
+    """Giant sectors are shared by a TEAM of 512-thread workgroups that exchange their partial
+    sums through global memory once per evaluation (kernel K1, "teams").  Forced here
+    on sectors small enough for the oracle (LK_FORCE_TEAM is read at commit): the records must
+    pass the same parity bars as any other lane group, and agree with the single-workgroup
+    engine far inside them (only the summation order differs)."""
+    rects = [(40, 40, 250, 250), (260, 40, 470, 260), (40, 270, 250, 470), (300, 300, 318, 318)]
+    lists = [oracle.rect_points(*r) for r in rects]
+    cens = np.array([((r[0] + r[2]) * 0.5, (r[1] + r[3]) * 0.5) for r in rects], np.float32)
+
+    def run():
+        e, o = make_pair(speckle512, ca.FM_UVUXUYVXVY, ca.IM_BICUBIC, oracle)
+        for s, r in enumerate(rects):
+            e.resetPolygon_rect(s, *r)
+        e.commit_sectors()
+        got = e.correlate_all(np.zeros(6, np.float32))
+        one, _ = e.correlate(1, np.zeros(6, np.float32))
+        assert one.tobytes() == got[1].tobytes()
+        e.close()
+        return got, o
+
+    plain, o = run()
+    monkeypatch.setenv("LK_FORCE_TEAM", str(width))
+    team, _ = run()
+    want = o.correlate_sectors(lists, centers=cens)
+    compare_results(team, want, f"team of {width}")
+    assert np.array_equal(team["error_code"], plain["error_code"])
+    assert np.array_equal(team["iterations"], plain["iterations"])
+    assert np.abs(team["p"] - plain["p"]).max() < 2e-5
+    assert (np.abs(team["chi"] - plain["chi"]) <= 1e-5 * np.abs(plain["chi"])).all()
