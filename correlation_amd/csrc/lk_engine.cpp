@@ -27,6 +27,9 @@ hipError_t lk_launch_solve_only(int n, const float *d_in, float *d_out, hipStrea
 hipError_t lk_launch_sample(int interp, const uint8_t *def, int rows, int cols, const float2 *pts, int n,
                             float4 *out, hipStream_t st);
 hipError_t lk_launch_pyramid(const uint8_t *src, int srows, int scols, uint8_t *dst, hipStream_t st);
+hipError_t lk_launch_set_views(const LkLevelView *h_views, LkLevelView *d_views, hipStream_t st);
+hipError_t lk_launch_pyramid2(const uint8_t *src, int step, int rows, int cols, uint8_t *l0, uint8_t *l1,
+                              uint8_t *l2, hipStream_t st);
 hipError_t lk_launch_guess(const float2 *center, const float *last_p, float *prev_p, float *guess,
                            const float *global_guess, float gcx, float gcy, int n_sectors, int model,
                            int frame, int constant_velocity, hipStream_t st);
@@ -118,11 +121,12 @@ struct lk_engine {
   hipStream_t own_stream = nullptr, stream = nullptr, nxt_stream = nullptr;
   hipEvent_t nxt_done = nullptr, ev_s0 = nullptr, ev_s1 = nullptr, ev_p0 = nullptr, ev_p1 = nullptr;
   bool nxt_pending = false, solve_timed = false, pyr_timed = false;
+  bool timing = true; // HIP events around pyramid builds and solves (lk_stats.solve_ms / pyramid_ms)
   std::mutex nxt_mu;
   std::string err;
 
   DevImage img[3];
-  LkLevelView h_lv[LK_MAX_LEVELS]{};
+  LkLevelView h_lv[LK_MAX_LEVELS]{}, h_lv_sent[LK_MAX_LEVELS]{};
   DevBuf<LkLevelView> d_lv;
   bool lv_dirty = true;
 
@@ -261,6 +265,13 @@ int lk_set_stream(lk_engine *e, void *hip_stream) {
   return LK_ERROR_NONE;
 }
 
+int lk_set_timing(lk_engine *e, int enabled) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  e->timing = enabled != 0;
+  return LK_ERROR_NONE;
+}
+
 int lk_synchronize(lk_engine *e) {
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
@@ -312,14 +323,27 @@ static int set_image_common(lk_engine *e, int slot, const void *src, bool src_on
     r /= 2;
     c /= 2;
   }
-  HIPCHK(hipMemcpy2DAsync(im.lvl[0], (size_t)cols, src, (size_t)step, (size_t)cols, (size_t)rows,
-                          src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-  const bool timed = slot != LK_IMG_NXT;
+  const bool timed = slot != LK_IMG_NXT && e->timing;
+  // two or more pyramid levels on a device-resident frame: upload copy + levels 1, 2 in ONE
+  // launch (lk_pyramid2_kernel); host frames are copied first and the kernel runs in place
+  const bool fused = e->cfg.py_stop >= 2 && rows >= 4 && cols >= 4;
+  if (!fused || !src_on_device)
+    HIPCHK(hipMemcpy2DAsync(im.lvl[0], (size_t)cols, src, (size_t)step, (size_t)cols, (size_t)rows,
+                            src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
   if (timed)
     HIPCHK(hipEventRecord(e->ev_p0, st));
   r = rows;
   c = cols;
-  for (int l = 1; l <= e->cfg.py_stop; ++l) { // all levels 1..stop (pyramid_class.cpp:92)
+  int l = 1;
+  if (fused) {
+    const bool in_place = !src_on_device;
+    HIPCHK(lk_launch_pyramid2(in_place ? im.lvl[0] : (const uint8_t *)src, in_place ? cols : step, rows, cols,
+                              im.lvl[0], im.lvl[1], im.lvl[2], st));
+    r = rows / 4;
+    c = cols / 4;
+    l = 3;
+  }
+  for (; l <= e->cfg.py_stop; ++l) { // (remaining) levels up to stop (pyramid_class.cpp:92)
     HIPCHK(lk_launch_pyramid(im.lvl[l - 1], r, c, im.lvl[l], st));
     r /= 2;
     c /= 2;
@@ -802,9 +826,14 @@ static int refresh_level_views(lk_engine *e) {
     v.drows = d.rows >> l;
     v.dcols = d.cols >> l;
   }
-  HIPCHK(e->d_lv.ensure(LK_MAX_LEVELS));
-  HIPCHK(hipMemcpyAsync(e->d_lv.p, e->h_lv, sizeof(e->h_lv), hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream)); // h_lv is pageable
+  // Same buffers and geometry as the last launch (a frame loop that reuses its slots): nothing
+  // to do.  Otherwise the table travels in the kernel arguments of a one-wavefront kernel:
+  // stream-ordered, no staging buffer, no host synchronisation between the frames.
+  if (!e->d_lv.p || std::memcmp(e->h_lv, e->h_lv_sent, sizeof(e->h_lv)) != 0) {
+    HIPCHK(e->d_lv.ensure(LK_MAX_LEVELS));
+    HIPCHK(lk_launch_set_views(e->h_lv, e->d_lv.p, e->stream));
+    std::memcpy(e->h_lv_sent, e->h_lv, sizeof(e->h_lv));
+  }
   e->lv_dirty = false;
   return LK_ERROR_NONE;
 }
@@ -826,7 +855,8 @@ static LkSolveArgs base_args(lk_engine *e, const float *d_guess, lk_result *d_re
 }
 
 static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
-  HIPCHK(hipEventRecord(e->ev_s0, e->stream));
+  if (e->timing)
+    HIPCHK(hipEventRecord(e->ev_s0, e->stream));
   for (int c = 0; c < kNumClasses; ++c) {
     int n = e->class_begin[c + 1] - e->class_begin[c];
     if (n <= 0)
@@ -847,8 +877,10 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
     }
     HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, kGroupOfClass[c], e->stream));
   }
-  HIPCHK(hipEventRecord(e->ev_s1, e->stream));
-  e->solve_timed = true;
+  if (e->timing) {
+    HIPCHK(hipEventRecord(e->ev_s1, e->stream));
+    e->solve_timed = true;
+  }
   e->stats_valid = false;
   return LK_ERROR_NONE;
 }
@@ -915,14 +947,17 @@ int lk_correlate(lk_engine *e, int sector, float *guess_inout, lk_result *out) {
     a.team_partials = e->d_team_partials.p;
     a.team_arrivals = e->d_team_arrivals.p;
   }
-  HIPCHK(hipEventRecord(e->ev_s0, e->stream));
+  if (e->timing)
+    HIPCHK(hipEventRecord(e->ev_s0, e->stream));
   if (e->class_starved[e->h_class[(size_t)sector]]) {
     a.handoff = e->d_handoff.p;
     HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, 1, e->stream));
   }
   HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, group, e->stream));
-  HIPCHK(hipEventRecord(e->ev_s1, e->stream));
-  e->solve_timed = true;
+  if (e->timing) {
+    HIPCHK(hipEventRecord(e->ev_s1, e->stream));
+    e->solve_timed = true;
+  }
   e->stats_valid = false;
   HIPCHK(hipMemcpyAsync(out, e->d_result.p + sector, sizeof(lk_result), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));

@@ -1237,6 +1237,126 @@ __global__ void __launch_bounds__(256) lk_pyramid_kernel(const uint8_t *__restri
   }
 }
 
+// the per-level table of image / sample-list pointers, delivered through kernel arguments
+struct LkLevelTable {
+  LkLevelView v[LK_MAX_LEVELS];
+};
+__global__ void lk_set_views_kernel(LkLevelTable t, LkLevelView *out) {
+  if (threadIdx.x < LK_MAX_LEVELS)
+    out[threadIdx.x] = t.v[threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------
+// fused upload + two pyramid levels: one launch per image instead of copy + 2 kernels.
+// A workgroup owns a 64x64 tile of level 0, the 32x32 tile of level 1 and the 16x16 tile of
+// level 2 below it.  It stages the 73x73 level-0 region those need in LDS (and copies its
+// own tile to the engine's level-0 buffer), computes the 35x35 level-1 values the level-2
+// tile reads (the halo ring is recomputed by the neighbours too: +20 % MACs, no exchange),
+// keeps them in LDS as u8, and finishes with its level-2 tile.  Arithmetic, order and
+// border rule are lk_pyramid_kernel's (pyramid_class.cpp:83-122), so every level is
+// bit-identical to the one-level kernel.
+// ------------------------------------------------------------------------------------
+constexpr int kPyrT0 = 64, kPyrR0 = 73, kPyrPitch0 = 80, kPyrR1 = 35, kPyrPitch1 = 36;
+
+__device__ __forceinline__ uint8_t pyr_tap(const uint8_t *win, int pitch) {
+  // 5x5 taps around win[2][2]; (dj outer, di inner), separate multiply and add
+  const float km[5] = {0.05f, 0.25f, 0.4f, 0.25f, 0.05f};
+  float acc = 0.f;
+#pragma unroll
+  for (int dj = 0; dj < 5; ++dj)
+#pragma unroll
+    for (int di = 0; di < 5; ++di)
+      acc += (float)win[dj * pitch + di] * (km[di] * km[dj]);
+  return (uint8_t)acc;
+}
+
+__global__ void __launch_bounds__(256) lk_pyramid2_kernel(const uint8_t *__restrict__ src, int step, int rows,
+                                                          int cols, uint8_t *__restrict__ l0,
+                                                          uint8_t *__restrict__ l1, uint8_t *__restrict__ l2) {
+  __shared__ __attribute__((aligned(16))) uint8_t s0[kPyrR0 * kPyrPitch0];
+  __shared__ __attribute__((aligned(16))) uint8_t s1[kPyrR1 * kPyrPitch1];
+  const int rows1 = rows / 2, cols1 = cols / 2, rows2 = rows1 / 2, cols2 = cols1 / 2;
+  const int x2 = (int)blockIdx.x * 16, y2 = (int)blockIdx.y * 16; // level-2 tile origin
+  const int X0 = 4 * x2 - 8, Y0 = 4 * y2 - 6;                       // level-0 region origin (X0 % 4 == 0)
+  const int tid = (int)threadIdx.x;
+  const bool copy0 = src != l0;
+  // ---- stage level 0 (zero outside the image: only border outputs would read it, and those are 0)
+  const bool dwords = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)step) & 3u) == 0 && (cols & 3) == 0;
+  for (int i = tid; i < kPyrR0 * (kPyrPitch0 / 4); i += 256) {
+    const int r = i / (kPyrPitch0 / 4), cw = i % (kPyrPitch0 / 4);
+    const int gy = Y0 + r, gx = X0 + 4 * cw;
+    uint32_t v = 0;
+    if (gy >= 0 && gy < rows) {
+      const uint8_t *row = src + (size_t)gy * (size_t)step;
+      if (dwords && gx >= 0 && gx + 4 <= cols) {
+        v = *reinterpret_cast<const uint32_t *>(row + gx);
+      } else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (gx + b >= 0 && gx + b < cols)
+            v |= (uint32_t)row[gx + b] << (8 * b);
+      }
+      // this workgroup's own 64x64 tile goes to the engine's level-0 image (pitch = cols)
+      if (copy0 && r >= 6 && r < 6 + kPyrT0 && cw >= 2 && cw < 2 + kPyrT0 / 4) {
+        uint8_t *out = l0 + (size_t)gy * (size_t)cols + (size_t)gx;
+        if ((cols & 3) == 0 && gx + 4 <= cols) {
+          *reinterpret_cast<uint32_t *>(out) = v;
+        } else {
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            if (gx + b < cols)
+              out[b] = (uint8_t)(v >> (8 * b));
+        }
+      }
+    }
+    reinterpret_cast<uint32_t *>(s0)[i] = v;
+  }
+  __syncthreads();
+  // ---- level 1: local (j, i) <-> global (2*y2 - 2 + j, 2*x2 - 2 + i); taps start at local
+  //      level-0 row 2*j, column 2*i + 2.  One task = 4 adjacent outputs of one row from a
+  //      5-row x 11-byte window (two 8-byte LDS reads per row), like lk_pyramid_kernel.
+  for (int t = tid; t < kPyrR1 * (kPyrPitch1 / 4); t += 256) {
+    const int j = t / (kPyrPitch1 / 4), i0 = 4 * (t % (kPyrPitch1 / 4));
+    const float km[5] = {0.05f, 0.25f, 0.4f, 0.25f, 0.05f};
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dj = 0; dj < 5; ++dj) {
+      const uint2 *w = reinterpret_cast<const uint2 *>(s0 + (2 * j + dj) * kPyrPitch0 + 2 * i0); // 8-byte aligned
+      const uint2 a = w[0], b = w[1];
+      const float px[11] = {ub2(a.x), ub3(a.x), ub0(a.y), ub1(a.y), ub2(a.y), ub3(a.y),
+                            ub0(b.x), ub1(b.x), ub2(b.x), ub3(b.x), ub0(b.y)};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int di = 0; di < 5; ++di)
+          acc[q] += px[2 * q + di] * (km[di] * km[dj]);
+    }
+    const int gj = 2 * y2 - 2 + j;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int gi = 2 * x2 - 2 + i0 + q;
+      const bool inside = gj >= 1 && gj < rows1 - 1 && gi >= 1 && gi < cols1 - 1;
+      const uint32_t v = inside ? (uint32_t)(uint8_t)acc[q] : 0u;
+      packed |= v << (8 * q);
+      if (j >= 2 && j < 34 && i0 + q >= 2 && i0 + q < 34 && gj < rows1 && gi < cols1)
+        l1[(size_t)gj * (size_t)cols1 + (size_t)gi] = (uint8_t)v;
+    }
+    *reinterpret_cast<uint32_t *>(s1 + j * kPyrPitch1 + i0) = packed;
+  }
+  __syncthreads();
+  // ---- level 2: one output per thread; taps start at local level-1 (2*j, 2*i)
+  {
+    const int j = tid / 16, i = tid % 16;
+    const int gj = y2 + j, gi = x2 + i;
+    if (gj < rows2 && gi < cols2) {
+      const bool inside = gj >= 1 && gj < rows2 - 1 && gi >= 1 && gi < cols2 - 1;
+      l2[(size_t)gj * (size_t)cols2 + (size_t)gi] =
+          inside ? pyr_tap(s1 + (2 * j) * kPyrPitch1 + 2 * i, kPyrPitch1) : (uint8_t)0;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // initial-guess policy for every sector (managerClass::adjust_initial_guess,
 // manager_class.cpp:2602-2707)
@@ -1350,6 +1470,11 @@ static hipError_t launch_solve_gs(const LkSolveArgs &a, hipStream_t st) {
   }
   b.team_w = 0;
   b.chunk = (want + 7) / 8;
+  if (b.persistent) { // rewind the sector queue
+    hipError_t qe = hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st);
+    if (qe != hipSuccess)
+      return qe;
+  }
   dim3 grid((unsigned)(b.persistent ? resident : 8 * b.chunk));
   hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, GROUP, THREADS, SAFE>), grid, dim3(THREADS), 0, st, b);
   return hipGetLastError();
@@ -1389,9 +1514,6 @@ static hipError_t launch_solve_m(const LkSolveArgs &a, int interp, int group, hi
 hipError_t lk_launch_solve(const LkSolveArgs &a, int model, int interp, int group, hipStream_t st) {
   if (a.n_sectors <= 0)
     return hipSuccess;
-  hipError_t qe = hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st); // rewind the sector queue
-  if (qe != hipSuccess)
-    return qe;
   switch (model) {
   case LK_FM_U: return launch_solve_m<LK_FM_U>(a, interp, group, st);
   case LK_FM_UV: return launch_solve_m<LK_FM_UV>(a, interp, group, st);
@@ -1460,6 +1582,24 @@ hipError_t lk_launch_pyramid(const uint8_t *src, int srows, int scols, uint8_t *
   dim3 block(64, 4);
   dim3 grid((unsigned)((tcols + 4 * 64 - 1) / (4 * 64)), (unsigned)((trows + 3) / 4));
   hipLaunchKernelGGL(lk_pyramid_kernel, grid, block, 0, st, src, srows, scols, dst);
+  return hipGetLastError();
+}
+
+hipError_t lk_launch_set_views(const LkLevelView *h_views, LkLevelView *d_views, hipStream_t st) {
+  LkLevelTable t;
+  for (int l = 0; l < LK_MAX_LEVELS; ++l)
+    t.v[l] = h_views[l];
+  hipLaunchKernelGGL(lk_set_views_kernel, dim3(1), dim3(64), 0, st, t, d_views);
+  return hipGetLastError();
+}
+
+// copy (src -> l0, skipped when src == l0) + levels 1 and 2 in one launch
+hipError_t lk_launch_pyramid2(const uint8_t *src, int step, int rows, int cols, uint8_t *l0, uint8_t *l1,
+                              uint8_t *l2, hipStream_t st) {
+  if (rows / 4 <= 0 || cols / 4 <= 0)
+    return hipErrorInvalidValue;
+  dim3 grid((unsigned)((cols + kPyrT0 - 1) / kPyrT0), (unsigned)((rows + kPyrT0 - 1) / kPyrT0));
+  hipLaunchKernelGGL(lk_pyramid2_kernel, grid, dim3(256), 0, st, src, step, rows, cols, l0, l1, l2);
   return hipGetLastError();
 }
 

@@ -70,6 +70,9 @@ class HipCorrelationEngine:
     def set_stream(self, hip_stream):
         self._chk(self.lib.lk_set_stream(self._h, C.c_void_p(hip_stream)))
 
+    def set_timing(self, enabled):
+        self._chk(self.lib.lk_set_timing(self._h, int(bool(enabled))))
+
     def synchronize(self):
         self._chk(self.lib.lk_synchronize(self._h))
 

@@ -94,6 +94,10 @@ void lk_destroy(lk_engine *e);
 const char *lk_last_error_string(const lk_engine *e);
 /* run all engine work on a caller-provided hipStream_t (NULL = engine's own stream) */
 int lk_set_stream(lk_engine *e, void *hip_stream);
+/* HIP events around pyramid builds and solves (the DEBUG_TIME_* prints of defines.hpp:29-72):
+ * on by default; off removes four event records per frame from the stream and leaves
+ * lk_stats.solve_ms / pyramid_ms at their last values */
+int lk_set_timing(lk_engine *e, int enabled);
 /* block until everything queued by this engine has finished */
 int lk_synchronize(lk_engine *e);
 

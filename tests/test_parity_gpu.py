@@ -158,6 +158,37 @@ def test_pyramid_bit_exact(oracle):
         e.close()
 
 
+def test_pyramid_from_device_frames_bit_exact(oracle):
+    """lk_set_image_device: the fused upload + two-level kernel reads the caller's device buffer
+    (any pitch, any alignment) and must give the same bytes at every level, also for 2- and
+    3-level pyramids and sizes that are not multiples of the 64-pixel tile."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")  # the runtime the engine library itself is linked to
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    rng = np.random.default_rng(6)
+    for shape, pad, shift, stop in (((64, 64), 0, 0, 2), ((98, 130), 6, 1, 2), ((131, 257), 3, 3, 3),
+                                    ((260, 200), 56, 4, 2), ((77, 90), 0, 2, 1)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        step = shape[1] + pad
+        host = np.full(shape[0] * step + 16, 255, np.uint8)  # pitch padding must never be read as pixels
+        host[shift:shift + shape[0] * step].reshape(shape[0], step)[:, :shape[1]] = img
+        e = ca.HipCorrelationEngine(py_stop=stop)
+        dev = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(dev), host.size) == 0
+        assert hip.hipMemcpy(dev, host.ctypes.data_as(ctypes.c_void_p), host.size, 1) == 0
+        e.set_image_device(ca.IMG_DEF, dev.value + shift, shape[0], shape[1], step)
+        e.synchronize()
+        assert hip.hipFree(dev) == 0
+        o = oracle.Oracle(py_stop=stop)
+        o.set_image(1, img)
+        for lvl in range(0, stop + 1):
+            got, want = e.get_pyramid_level(ca.IMG_DEF, lvl), o.get_level(1, lvl)
+            assert np.array_equal(got, want), (shape, lvl, np.count_nonzero(got != want))
+        e.close()
+
+
 @pytest.mark.parametrize("interp", [ca.IM_NEAREST, ca.IM_BILINEAR, ca.IM_BICUBIC])
 def test_sampling_bit_exact(oracle, speckle512, interp):
     und, dfm = speckle512
