@@ -56,6 +56,7 @@ SYMBOLS = {
     "lk_last_error_string": (C.c_char_p, [_P]),
     "lk_set_stream": (C.c_int, [_P, _P]),
     "lk_set_timing": (C.c_int, [_P, C.c_int]),
+    "lk_set_batch_invariant": (C.c_int, [_P, C.c_int]),
     "lk_synchronize": (C.c_int, [_P]),
     "lk_set_image": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "lk_set_image_device": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int]),

@@ -45,6 +45,7 @@ struct LkSolveArgs {
   uint32_t *queue;       // next unclaimed slot of this launch (persistent mode), zeroed per launch
   int n_sectors;         // sectors in this launch
   int chunk;             // non-persistent: ceil(#workgroups / 8), XCD-contiguous chunk length
+  int solo;              // 1: an idle half-wavefront may join its partner's sector (32-lane groups)
   int safe;              // 1: reference-exact handling of starved / ill-conditioned levels
   int persistent;        // 1: groups pull sectors from `queue`; 0: one sector per group by position
   int py_start, py_step, py_stop;

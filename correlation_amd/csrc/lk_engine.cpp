@@ -121,6 +121,7 @@ struct lk_engine {
   hipStream_t own_stream = nullptr, stream = nullptr, nxt_stream = nullptr;
   hipEvent_t nxt_done = nullptr, ev_s0 = nullptr, ev_s1 = nullptr, ev_p0 = nullptr, ev_p1 = nullptr;
   bool nxt_pending = false, solve_timed = false, pyr_timed = false;
+  bool batch_invariant = false; // lk_set_batch_invariant
   bool timing = true; // HIP events around pyramid builds and solves (lk_stats.solve_ms / pyramid_ms)
   std::mutex nxt_mu;
   std::string err;
@@ -269,6 +270,13 @@ int lk_set_timing(lk_engine *e, int enabled) {
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
   e->timing = enabled != 0;
+  return LK_ERROR_NONE;
+}
+
+int lk_set_batch_invariant(lk_engine *e, int enabled) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  e->batch_invariant = enabled != 0;
   return LK_ERROR_NONE;
 }
 
@@ -851,6 +859,7 @@ static LkSolveArgs base_args(lk_engine *e, const float *d_guess, lk_result *d_re
   a.py_stop = e->cfg.py_stop;
   a.precision = e->cfg.precision;
   a.max_iters = e->cfg.max_iters;
+  a.solo = e->batch_invariant ? 0 : 1;
   return a;
 }
 

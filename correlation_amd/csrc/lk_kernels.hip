@@ -279,11 +279,16 @@ struct TeamCtx {
 
 template <int MODEL, int INTERP, int GROUP, int THREADS>
 __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
-                                         Sums<n_params(MODEL)> &S, float *lds, TeamCtx *team = nullptr) {
+                                         Sums<n_params(MODEL)> &S, float *lds, TeamCtx *team = nullptr,
+                                         bool wide = false) {
   constexpr int P = n_params(MODEL);
   using SumsT = Sums<P>;
   const int team_w = (GROUP == 512 && team) ? team->w : 1;
   const int team_rank = (GROUP == 512 && team) ? team->rank : 0;
+  // GROUP == 32, `wide` (wavefront-uniform): the partner half-wavefront has run out of work
+  // and both halves evaluate the same sector with all 64 lanes (see "solo" in the kernel)
+  const int lane0 = (GROUP == 32 && wide) ? ((int)threadIdx.x & 63) : team_rank * GROUP + (int)threadIdx.x % GROUP;
+  const int stride = (GROUP == 32 && wide) ? 64 : GROUP * team_w;
 #pragma unroll
   for (int i = 0; i < SumsT::N; ++i)
     S.v[i] = 0.f;
@@ -299,7 +304,7 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
   // bit-identical to the reference's.
   const float inv_w = c.rw > 0 ? 1.f / (float)c.rw : 0.f;
   const int rh = (GROUP == 1 && c.rw > 0) ? c.n / c.rw : 1; // height of the implicit rectangle
-  for (int k = team_rank * GROUP + (int)threadIdx.x % GROUP; k < c.n; k += GROUP * team_w) {
+  for (int k = lane0; k < c.n; k += stride) {
     f32x2 q;
     if (GROUP == 1 && c.rw > 0) { // reference order: x outer, y inner
       const int col = k / rh;
@@ -370,6 +375,12 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
 #pragma unroll
     for (int i = 0; i < SumsT::N; ++i)
       S.v[i] += __shfl_xor(S.v[i], 16, 64);
+    if (wide) { // a + b == b + a: both halves end with the same bits
+#pragma unroll
+      for (int i = 0; i < SumsT::N; ++i)
+        S.v[i] += __shfl_xor(S.v[i], 32, 64);
+      return badmask != 0ull;
+    }
     const int half = ((int)threadIdx.x & 63) >> 5;
     return ((badmask >> (32 * half)) & 0xffffffffull) != 0ull;
   } else {
@@ -818,7 +829,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
   constexpr int RED_WORDS = GROUP > kWave ? (THREADS / kWave) * (SumsT::N + 1) + 1 : 1;
   __shared__ float lds[RED_WORDS];
   __shared__ uint32_t cold_lds[COLD_IN_LDS ? (THREADS / GROUP) * kColdWords : 1];
-  uint32_t *const cold_slot = cold_lds + (COLD_IN_LDS ? ((int)threadIdx.x / GROUP) * kColdWords : 0);
+  uint32_t *cold_slot = cold_lds + (COLD_IN_LDS ? ((int)threadIdx.x / GROUP) * kColdWords : 0);
   ColdStore<COLD_IN_LDS> cold;
 
   float p[6];
@@ -830,6 +841,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
   int phase = PH_FETCH;
   LevelCtx c{};
   SumsT S;
+  bool wide = false; // GROUP == 32 only: both halves of the wavefront work on one sector
   TeamCtx team;
   if constexpr (GROUP == 512) {
     if (a.team_w > 1) {
@@ -984,18 +996,53 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
         phase = PH_EXIT;
       }
     }
-    const bool active = phase < PH_FETCH;
+    bool active = phase < PH_FETCH;
     if constexpr (GROUP >= kWave) {
       if (!active)
         break; // uniform over the workgroup: nothing left to do
     } else {
-      if (__ballot(active) == 0ull)
+      const unsigned long long act = __ballot(active);
+      if (act == 0ull)
         break; // every group of this wavefront is out of work
+      if constexpr (GROUP == 32) {
+        // Solo: one half-wavefront is out of work for good (PH_EXIT) while its partner is still
+        // solving - typically a sector that needs many more evaluations than its neighbour.
+        // The idle half adopts the partner's sector: it copies the warm state (parameters,
+        // level context, phase), shares the partner's cold slot, and from here on both halves
+        // run the identical state machine on identical sums while every evaluation uses all
+        // 64 lanes.  Duplicate stores (cold slot, final record) write identical values.
+        const bool lo = (uint32_t)act != 0u, hi = (uint32_t)(act >> 32) != 0u;
+        if (a.solo && !wide && lo != hi && __ballot(phase == PH_EXIT) == ~act) {
+          auto take = [&](auto &v) {
+            const auto other = __shfl_xor(v, 32, 64);
+            if (!active)
+              v = other;
+          };
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+            take(p[i]);
+          take(c.rx), take(c.ry), take(c.rw), take(c.n);
+          take(c.urows), take(c.ucols), take(c.drows), take(c.dcols);
+          take(c.scaling), take(c.cx), take(c.cy);
+          auto take_ptr = [&](auto &ptr) {
+            unsigned long long bits = (unsigned long long)(uintptr_t)ptr;
+            uint32_t lo32 = (uint32_t)bits, hi32 = (uint32_t)(bits >> 32);
+            take(lo32), take(hi32);
+            ptr = (decltype(+ptr))(uintptr_t)(((unsigned long long)hi32 << 32) | lo32);
+          };
+          take_ptr(c.und), take_ptr(c.def), take_ptr(c.xy);
+          take(phase);
+          if (!active)
+            cold_slot = cold_lds + (((int)threadIdx.x / GROUP) ^ 1) * kColdWords;
+          active = true;
+          wide = true;
+        }
+      }
     }
     LevelCtx ce = c;
     if (!active)
       ce.n = 0;
-    const bool err = evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds, &team);
+    const bool err = evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds, &team, wide);
     if (active) {
       Cold k = cold.load(cold_slot);
       ++k.n_evals;

@@ -73,6 +73,9 @@ class HipCorrelationEngine:
     def set_timing(self, enabled):
         self._chk(self.lib.lk_set_timing(self._h, int(bool(enabled))))
 
+    def set_batch_invariant(self, enabled):
+        self._chk(self.lib.lk_set_batch_invariant(self._h, int(bool(enabled))))
+
     def synchronize(self):
         self._chk(self.lib.lk_synchronize(self._h))
 

@@ -98,6 +98,13 @@ int lk_set_stream(lk_engine *e, void *hip_stream);
  * on by default; off removes four event records per frame from the stream and leaves
  * lk_stats.solve_ms / pyramid_ms at their last values */
 int lk_set_timing(lk_engine *e, int enabled);
+/* A sector's record is always deterministic for a given batch.  By default it may differ in
+ * the last bits between batches of different composition (a half-wavefront that runs out of
+ * work joins its neighbour's sector, which changes the summation grouping - the same kind of
+ * difference the reference shows between thread counts, correlation_class.cpp:169-186,253-275).
+ * enabled = 1 switches that off: a sector then gets the same bits in any batch, shard or
+ * single-sector call (about 20 % slower on small grids). */
+int lk_set_batch_invariant(lk_engine *e, int enabled);
 /* block until everything queued by this engine has finished */
 int lk_synchronize(lk_engine *e);
 

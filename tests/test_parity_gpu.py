@@ -632,3 +632,35 @@ def test_team_of_workgroups_per_sector(oracle, speckle512, width, monkeypatch):
     assert np.array_equal(team["iterations"], plain["iterations"])
     assert np.abs(team["p"] - plain["p"]).max() < 2e-5
     assert (np.abs(team["chi"] - plain["chi"]) <= 1e-5 * np.abs(plain["chi"])).all()
+
+
+@pytest.mark.gpu
+def test_solo_half_wavefronts(oracle, speckle512, monkeypatch):
+    """32-lane groups: a half-wavefront that has run out of work joins its partner's sector
+    ("solo").  Same parity bars as everything else; against the
+    batch-invariant mode only the summation grouping differs; and in batch-invariant mode a
+    sector gets the same bits alone, in a shard with other neighbours, and in the full batch."""
+    monkeypatch.setenv("LK_FORCE_GROUP", "32")
+    xdim, ydim, cen = oracle.rect_sector_geometry(24.0, 24.0, 487.0, 487.0, 11, 11)
+    lists = [oracle.rect_points(cx - xdim, cy - ydim, cx + xdim, cy + ydim) for cx, cy in cen]
+
+    def run(invariant, first=0, count=-1):
+        e, o = make_pair(speckle512, ca.FM_UVUXUYVXVY, ca.IM_BICUBIC, oracle)
+        e.set_batch_invariant(invariant)
+        e.set_rect_grid(24.0, 24.0, 487.0, 487.0, 11, 11, first, count)
+        e.commit_sectors()
+        got = e.correlate_all(np.zeros(6, np.float32))
+        one, _ = e.correlate(3, np.zeros(6, np.float32))
+        e.close()
+        return got, one, o
+
+    solo, _, o = run(False)
+    inv, inv_one, _ = run(True)
+    want = o.correlate_sectors(lists, centers=np.array(cen, np.float32))
+    compare_results(solo, want, "solo half-wavefronts")
+    compare_results(inv, want, "batch-invariant")
+    assert np.array_equal(solo["error_code"], inv["error_code"])
+    assert np.abs(solo["p"] - inv["p"])[:, :2].max() < 5e-3
+    assert inv_one.tobytes() == inv[3].tobytes()
+    shard, _, _ = run(True, 37, 51)      # odd start: every sector has a different partner
+    assert shard.tobytes() == inv[37:88].tobytes()
