@@ -41,7 +41,7 @@ def build(force=False, verbose=False):
         # to the sample loop (measured: 6 % slower with it)
         "-fno-slp-vectorize",
         "-Wall", "-Wextra", "-o", LIB,
-    ] + SOURCES
+    ] + os.environ.get("LK_EXTRA_HIPCC_FLAGS", "").split() + SOURCES  # (tuning experiments)
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
