@@ -11,3 +11,4 @@ from ._ffi import (ERROR_BAD_DOMAIN, ERROR_CORRELATION_MAX_ITERS_REACHED, ERROR_
                    LIB_PATH, N_PARAMS, RESULT_DTYPE, SYMBOLS, load_library)
 from .engine import HipCorrelationEngine, LkError  # noqa: F401
 from . import speckle  # noqa: F401
+from . import tracker  # noqa: F401

@@ -72,6 +72,10 @@ SYMBOLS = {
     "lk_set_sector_blob": (C.c_int, [_P, C.c_int, _F, C.c_int]),
     "lk_set_sector_points": (C.c_int, [_P, C.c_int, _F, C.c_int, C.c_int, C.c_float, C.c_float]),
     "lk_commit_sectors": (C.c_int, [_P]),
+    "lk_translate_sectors": (C.c_int, [_P, _F, _F]),
+    "lk_rewarp_sectors": (C.c_int, [_P, _F]),
+    "lk_restore_sectors": (C.c_int, [_P, C.c_int]),
+    "lk_get_last_evaluated_parameters": (C.c_int, [_P, _F]),
     "lk_sector_count": (C.c_int, [_P]),
     "lk_get_sector_info": (C.c_int, [_P, C.c_int, _I, _F, _F]),
     "lk_get_sector_level_count": (C.c_int, [_P, C.c_int, C.c_int, _I]),
@@ -86,6 +90,24 @@ SYMBOLS = {
     "lk_sample": (C.c_int, [_P, C.c_int, C.c_int, _F, C.c_int, _F]),
     "lk_damped_solve": (C.c_int, [_P, C.c_int, _F, _F, C.c_float, C.c_float, C.c_int, _F]),
     "lk_get_stats": (C.c_int, [_P, C.POINTER(LkStats)]),
+    # include/lk_tracker.h
+    "lk_tracker_create": (C.c_int, [_P, C.POINTER(_P)]),
+    "lk_tracker_destroy": (None, [_P]),
+    "lk_tracker_last_error": (C.c_char_p, [_P]),
+    "lk_tracker_set_rect_domain": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                             C.c_int, C.c_int]),
+    "lk_tracker_set_annular_domain": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]),
+    "lk_tracker_set_blob_domain": (C.c_int, [_P, _F, C.c_int, C.c_float, C.c_float]),
+    "lk_tracker_sector_count": (C.c_int, [_P]),
+    "lk_tracker_blob_contour": (C.c_int, [_P, C.POINTER(_F), _I]),
+    "lk_tracker_begin_frame": (C.c_int, [_P, C.c_int, _P, _F]),
+    "lk_tracker_end_frame": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_char_p, _P, _I, _I]),
+    "lk_tracker_get_results": (C.c_int, [_P, _P]),
+    "lk_tracker_report": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "lk_sequence_frame": (C.c_int, [_P, _P, C.c_int, C.c_char_p, C.c_char_p, _I]),
+    "lk_sequence_run": (C.c_int, [_P, _P, C.c_int, _P, _P, _I]),
+    "lk_load_pgm": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), _I, _I]),
+    "lk_free_image": (None, [C.POINTER(C.c_uint8)]),
 }
 
 

@@ -9,8 +9,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblk_engine.so")
-SOURCES = ["lk_engine.cpp", "lk_kernels.hip"]
-HEADERS = ["lk_device.hpp", "lk_roi.hpp", os.path.join("..", "..", "include", "lk_engine.h")]
+SOURCES = ["lk_engine.cpp", "lk_tracker.cpp", "lk_kernels.hip"]
+HEADERS = ["lk_device.hpp", "lk_roi.hpp", os.path.join("..", "..", "include", "lk_engine.h"),
+           os.path.join("..", "..", "include", "lk_tracker.h")]
 
 
 def hipcc_path():

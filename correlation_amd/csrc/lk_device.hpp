@@ -35,6 +35,8 @@ struct LkSolveArgs {
   const float *guess;    // [S][6]
   lk_result *result;     // [S]
   float *last_p;         // [S][6] copy of the returned parameters (sequence state), may be null
+  float *last_eval_p;    // [S][6] parameters of the LAST evaluation at level 0 - what CorrelationClass::getDefXY0
+                         //   warps with (correlation_class.cpp:884-896); may be null
   uint32_t *stats;       // [S][4]: evaluations, sample evaluations, point iterations, -
   const uint32_t *order; // optional [n_sectors] indirection (size classes), may be null
   // teams: a giant sector is shared by team_w workgroups of the 512-thread kernel (0/1: off)

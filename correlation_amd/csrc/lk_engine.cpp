@@ -132,6 +132,7 @@ struct lk_engine {
   bool lv_dirty = true;
 
   std::vector<HostSector> hs; // staging until commit
+  std::vector<HostSector> hs_backup; // the lists before the last lk_translate / lk_rewarp_sectors
   bool committed = false;
   int S = 0;
   std::vector<uint32_t> h_off[LK_MAX_LEVELS];
@@ -141,7 +142,7 @@ struct lk_engine {
   std::vector<int4> h_rect[LK_MAX_LEVELS];
   std::vector<float> h_center; // [S][2]
   DevBuf<float2> d_center;
-  DevBuf<float> d_guess, d_last_p, d_prev_p;
+  DevBuf<float> d_guess, d_last_p, d_prev_p, d_last_eval_p;
   DevBuf<lk_result> d_result;
   DevBuf<uint32_t> d_stats;
   DevBuf<uint32_t> d_order;
@@ -236,6 +237,7 @@ void lk_destroy(lk_engine *e) {
   e->d_center.release();
   e->d_guess.release();
   e->d_last_p.release();
+  e->d_last_eval_p.release();
   e->d_prev_p.release();
   e->d_result.release();
   e->d_stats.release();
@@ -558,9 +560,9 @@ int lk_set_sector_points(lk_engine *e, int sector, const float *xy, int n, int u
   return LK_ERROR_NONE;
 }
 
-int lk_commit_sectors(lk_engine *e) {
-  if (!e)
-    return LK_ERROR_BAD_DOMAIN;
+// keep_state: a re-commit after the sample lists moved (Lagrangian descriptions) keeps the
+// sequence state of the sectors (guess history, last results)
+static int commit_impl(lk_engine *e, bool keep_state) {
   const int S = (int)e->hs.size();
   if (S == 0)
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_commit_sectors: no sectors");
@@ -637,10 +639,14 @@ int lk_commit_sectors(lk_engine *e) {
   HIPCHK(e->d_prev_p.ensure(6 * (size_t)S));
   HIPCHK(e->d_result.ensure((size_t)S));
   HIPCHK(e->d_stats.ensure(4 * (size_t)S));
-  HIPCHK(hipMemset(e->d_guess.p, 0, 6 * (size_t)S * sizeof(float)));
-  HIPCHK(hipMemset(e->d_last_p.p, 0, 6 * (size_t)S * sizeof(float)));
-  HIPCHK(hipMemset(e->d_prev_p.p, 0, 6 * (size_t)S * sizeof(float)));
-  HIPCHK(hipMemset(e->d_stats.p, 0, 4 * (size_t)S * sizeof(uint32_t)));
+  HIPCHK(e->d_last_eval_p.ensure(6 * (size_t)S));
+  if (!keep_state || S != e->S) {
+    HIPCHK(hipMemset(e->d_guess.p, 0, 6 * (size_t)S * sizeof(float)));
+    HIPCHK(hipMemset(e->d_last_p.p, 0, 6 * (size_t)S * sizeof(float)));
+    HIPCHK(hipMemset(e->d_prev_p.p, 0, 6 * (size_t)S * sizeof(float)));
+    HIPCHK(hipMemset(e->d_last_eval_p.p, 0, 6 * (size_t)S * sizeof(float)));
+    HIPCHK(hipMemset(e->d_stats.p, 0, 4 * (size_t)S * sizeof(uint32_t)));
+  }
   // size classes -> lanes per sector.  A class whose sectors are too few to fill the chip
   // (< 2048 wavefronts) and still large per lane is promoted to the next wider group.
   e->h_class.assign((size_t)S, 0);
@@ -730,6 +736,120 @@ int lk_commit_sectors(lk_engine *e) {
   e->committed = true;
   e->lv_dirty = true;
   e->stats_valid = false;
+  return LK_ERROR_NONE;
+}
+
+int lk_commit_sectors(lk_engine *e) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  return commit_impl(e, false);
+}
+
+// Lagrangian description, CPU-engine semantics (manager_class.cpp:381-419): every sample of
+// the sector moves by add_pair(offset), i.e. (int)(offset + v + 0.5f) per coordinate
+// (manager_class.cpp:38-47).  A rectangle whose columns and rows all move by one integer
+// stays an implicit rectangle; otherwise the sector becomes an explicit list.
+int lk_translate_sectors(lk_engine *e, const float *offsets_xy, const float *centers_xy) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!e->committed || !offsets_xy)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_translate_sectors: sectors are not committed");
+  e->hs_backup = e->hs;
+  for (int s = 0; s < e->S; ++s) {
+    HostSector &h = e->hs[(size_t)s];
+    const float ox = offsets_xy[2 * (size_t)s], oy = offsets_xy[2 * (size_t)s + 1];
+    if (h.is_rect) {
+      const int sx = (int)lkroi::add_pair_round(ox, (float)h.x0) - h.x0;
+      const int sy = (int)lkroi::add_pair_round(oy, (float)h.y0) - h.y0;
+      bool uniform = true;
+      for (int x = h.x0; x <= h.x1 && uniform; ++x)
+        uniform = (int)lkroi::add_pair_round(ox, (float)x) - x == sx;
+      for (int y = h.y0; y <= h.y1 && uniform; ++y)
+        uniform = (int)lkroi::add_pair_round(oy, (float)y) - y == sy;
+      if (uniform) {
+        h.x0 += sx, h.x1 += sx, h.y0 += sy, h.y1 += sy;
+      } else {
+        h.xy = h.points();
+        h.is_rect = false;
+      }
+    }
+    if (!h.is_rect) {
+      const size_t n = h.xy.size() / 2;
+      for (size_t i = 0; i < n; ++i) {
+        h.xy[2 * i] = lkroi::add_pair_round(ox, h.xy[2 * i]);
+        h.xy[2 * i + 1] = lkroi::add_pair_round(oy, h.xy[2 * i + 1]);
+      }
+    }
+    if (centers_xy) {
+      h.cx = centers_xy[2 * (size_t)s];
+      h.cy = centers_xy[2 * (size_t)s + 1];
+    } else { // Newton_Raphson(p, n, xy): float mean of the samples (pyramid_class.cpp:325-340)
+      const std::vector<float> pts = h.points();
+      lkroi::mean_center(pts.data(), (int)(pts.size() / 2), h.cx, h.cy);
+    }
+  }
+  return commit_impl(e, true);
+}
+
+// Strict Lagrangian description (manager_class.cpp:369-380): the deformed positions of the
+// last solve - CorrelationClass::getDefXY0, i.e. the samples warped with the parameters of
+// the LAST level-0 evaluation about the solve's centre (correlation_class.cpp:884-896) -
+// become the undeformed samples of the next frame.
+int lk_rewarp_sectors(lk_engine *e, const float *centers_xy) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!e->committed)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_rewarp_sectors: sectors are not committed");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  std::vector<float> ev(6 * (size_t)e->S);
+  HIPCHK(hipMemcpyAsync(ev.data(), e->d_last_eval_p.p, ev.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->hs_backup = e->hs;
+  for (int s = 0; s < e->S; ++s) {
+    HostSector &h = e->hs[(size_t)s];
+    if (h.is_rect) {
+      h.xy = h.points();
+      h.is_rect = false;
+    }
+    const size_t n = h.xy.size() / 2;
+    const float *p = &ev[6 * (size_t)s];
+    const float cx = h.cx, cy = h.cy;
+    for (size_t i = 0; i < n; ++i) {
+      float xd, yd;
+      lkroi::warp_point(e->cfg.fitting_model, h.xy[2 * i], h.xy[2 * i + 1], cx, cy, p, xd, yd);
+      h.xy[2 * i] = xd;
+      h.xy[2 * i + 1] = yd;
+    }
+    if (centers_xy) {
+      h.cx = centers_xy[2 * (size_t)s];
+      h.cy = centers_xy[2 * (size_t)s + 1];
+    } else {
+      lkroi::mean_center(h.xy.data(), (int)n, h.cx, h.cy);
+    }
+  }
+  return commit_impl(e, true);
+}
+
+// Sectors the manager's loop never reached on a frame that stopped at an error
+// (manager_class.cpp:520-546) keep the samples of the previous frame.
+int lk_restore_sectors(lk_engine *e, int first_sector) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!e->committed || first_sector < 0 || e->hs_backup.size() != e->hs.size())
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_restore_sectors: nothing to restore");
+  for (size_t s = (size_t)first_sector; s < e->hs.size(); ++s)
+    e->hs[s] = e->hs_backup[s];
+  return commit_impl(e, true);
+}
+
+int lk_get_last_evaluated_parameters(lk_engine *e, float *out) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!e->committed || !out)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_last_evaluated_parameters: sectors are not committed");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipMemcpyAsync(out, e->d_last_eval_p.p, 6 * (size_t)e->S * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
   return LK_ERROR_NONE;
 }
 
@@ -853,6 +973,7 @@ static LkSolveArgs base_args(lk_engine *e, const float *d_guess, lk_result *d_re
   a.guess = d_guess;
   a.result = d_result;
   a.last_p = e->d_last_p.p;
+  a.last_eval_p = e->d_last_eval_p.p;
   a.stats = e->d_stats.p;
   a.py_start = e->cfg.py_start;
   a.py_step = e->cfg.py_step;

@@ -903,7 +903,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
     phase = PH_EVAL0;
   };
 
-  auto finish_sector = [&](const Cold &k) { // results of Newton_Raphson (:638-639, :848-870)
+  auto finish_sector = [&](const Cold &k, const float (&evaluated)[6]) { // results of Newton_Raphson (:638-639, :848-870)
     if ((int)threadIdx.x % GROUP == 0 && team.rank == 0) {
       lk_result r;
 #pragma unroll
@@ -921,6 +921,12 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
 #pragma unroll
         for (int i = 0; i < 6; ++i)
           a.last_p[(size_t)k.s * 6 + i] = r.resultingParameters[i];
+      }
+      if (a.last_eval_p) { // def_xy_positions of the last level-0 evaluation (getDefXY0, :884-896);
+                           // with py_start > 0 the reference re-applies the returned parameters
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+          a.last_eval_p[(size_t)k.s * 6 + i] = a.py_start == 0 ? evaluated[i] : r.resultingParameters[i];
       }
       if (a.stats) {
         a.stats[(size_t)k.s * 4 + 0] = k.n_evals;
@@ -1045,6 +1051,11 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
     const bool err = evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds, &team, wide);
     if (active) {
       Cold k = cold.load(cold_slot);
+      float evaluated[6]; // the parameters this evaluation ran at, in level-0 scale
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        evaluated[i] = p[i];
+      translate<P>(evaluated, k.level, 0);
       ++k.n_evals;
       k.n_sample_evals += (uint32_t)c.n;
       bool level_end = false, iter_start = false, finished = false, handed = false;
@@ -1125,7 +1136,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
         }
       }
       if (finished)
-        finish_sector(k);
+        finish_sector(k, evaluated);
       else if (handed)
         hand_over(k);
       else

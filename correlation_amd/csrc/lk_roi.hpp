@@ -306,4 +306,31 @@ inline void mean_center(const float *xy, int n, float &cx, float &cy) {
   cy = sy / (float)n;
 }
 
+// the warp of one sample (ModelClass_*::compute_model, model_class.cpp:48-202), host side:
+// same operation order as the device code, no contraction (-ffp-contract=off)
+inline void warp_point(int model, float x, float y, float cx, float cy, const float *p, float &xd, float &yd) {
+  const float dx = x - cx, dy = y - cy;
+  switch (model) {
+  case 0: // fm_U
+    xd = x + p[0];
+    yd = y;
+    break;
+  case 1: // fm_UV
+    xd = x + p[0];
+    yd = y + p[1];
+    break;
+  case 2: // fm_UVQ
+    xd = x + p[0] - p[2] * dy;
+    yd = y + p[1] + p[2] * dx;
+    break;
+  default: // fm_UVUxUyVxVy
+    xd = x + p[0] + p[2] * dx + p[3] * dy;
+    yd = y + p[1] + p[4] * dx + p[5] * dy;
+    break;
+  }
+}
+
+// the functor the manager moves Lagrangian sample lists with (manager_class.cpp:38-47)
+inline float add_pair_round(float offset, float v) { return (float)(int)(offset + v + 0.5f); }
+
 } // namespace lkroi

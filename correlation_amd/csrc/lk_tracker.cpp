@@ -1,0 +1,678 @@
+// lk_tracker.cpp - sequence / tracking bookkeeping and frame loop (include/lk_tracker.h).
+//
+// Host code only.  The arithmetic that decides sector positions and guesses is float32 in the
+// reference's operation order (this file is compiled with -ffp-contract=off like the rest
+// of the library); the report goes through std::ostream with default flags, as the
+// reference's does (manager_class.cpp:2430-2471).
+#include "../../include/lk_tracker.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <future>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "lk_roi.hpp"
+
+namespace {
+const float kPI = 3.14159265359f; // parameters.hpp:23
+
+int n_params(int model) { return model == LK_FM_U ? 1 : model == LK_FM_UV ? 2 : model == LK_FM_UVQ ? 3 : 6; }
+} // namespace
+
+struct lk_tracker {
+  lk_tracker_config cfg{};
+  int P = 0;
+  bool domain_set = false;
+  // rectangularDomainStruct / annularDomainStruct / blobDomainStruct
+  float x_begin = 0, y_begin = 0, x_end = 0, y_end = 0, x_center = 0, y_center = 0;
+  int hs = 0, vs = 0;
+  float r_inside = 0, r_outside = 0;
+  int rs = 0, as = 0;
+  std::vector<float> contour;
+  int results_i = 0, results_j = 0;
+  std::vector<lk_frame_result> res, before; // frame_results[]; state before begin_frame
+  std::vector<lk_sector_command> last_cmds;
+  std::ostringstream report;
+  std::string report_cache, err;
+  bool begun = false;
+
+  int fail(int code, const char *what) {
+    err = what;
+    return code;
+  }
+};
+
+static void initialize_report(lk_tracker *t) { // manager_class.cpp:2473-2525
+  std::ostringstream &r = t->report;
+  r.str("");
+  r << "Frame#"
+    << ","
+    << "und_file_string"
+    << ","
+    << "def_file_string"
+    << ","
+    << "und_global_center_x"
+    << ","
+    << "und_global_center_y"
+    << ","
+    << "und_center_x"
+    << ","
+    << "und_center_y"
+    << ","
+    << "def_global_center_x"
+    << ","
+    << "def_global_center_y"
+    << ","
+    << "def_center_x"
+    << ","
+    << "def_center_y"
+    << ",";
+  for (int p = 0; p < t->P; ++p)
+    r << "parameter_" << p << ",";
+  for (int p = 0; p < t->P; ++p)
+    r << "Initial_guess_" << p << ",";
+  r << "und_global_angle(rad)"
+    << ","
+    << "def_global_angle(rad)"
+    << ","
+    << "und_angle(rad)"
+    << ","
+    << "def_angle(rad)"
+    << ","
+    << "def_angle(deg)"
+    << ",";
+  r << "chi"
+    << ","
+    << "number_of_points"
+    << ","
+    << "iterations"
+    << ","
+    << "error_status"
+    << ","
+    << "error_code" << std::endl;
+}
+
+static void add_frame_to_report(lk_tracker *t, int frame, const char *und, const char *def) { // :2430-2471
+  std::ostringstream &r = t->report;
+  for (const lk_frame_result &s : t->res) {
+    r << frame << "," << und << "," << def << "," << s.und_global_center_x << "," << s.und_global_center_y << ","
+      << s.und_center_x << "," << s.und_center_y << "," << s.def_global_center_x << "," << s.def_global_center_y
+      << "," << s.def_center_x << "," << s.def_center_y << ",";
+    for (int p = 0; p < t->P; ++p)
+      r << s.resulting_parameters[p] << ",";
+    for (int p = 0; p < t->P; ++p)
+      r << s.initial_guess[p] << ",";
+    r << s.und_global_angle << "," << s.def_global_angle << "," << s.und_angle << "," << s.def_angle << ","
+      << s.def_angle * 180 / kPI << ",";
+    r << s.chi << "," << s.number_of_points << "," << s.iterations << "," << (s.error_status != 0) << ","
+      << s.error_code << std::endl;
+  }
+}
+
+// the Lagrangian branch shared by adjust_rectangular/annular/blob_domain
+static void lagrangian_roll(lk_frame_result &s, bool annulus) {
+  s.und_global_center_x = s.def_global_center_x;
+  s.und_global_center_y = s.def_global_center_y;
+  if (annulus) {
+    s.und_global_ro = s.def_global_ro;
+    s.und_global_ri = s.def_global_ri;
+    s.und_global_e = s.def_global_e;
+  }
+  s.und_global_angle = s.def_global_angle;
+  s.past_und_center_x = s.und_center_x;
+  s.past_und_center_y = s.und_center_y;
+  s.und_center_x = s.def_center_x;
+  s.und_center_y = s.def_center_y;
+  if (annulus)
+    s.und_e = s.def_e;
+  s.und_angle = s.def_angle;
+}
+
+static void adjust_initial_guess(lk_tracker *t, lk_frame_result &s, int frame, float *guess_out) { // :2602-2707
+  const int P = t->P;
+  const float *g = t->cfg.global_guess;
+  if (frame == 0) {
+    for (int p = 0; p < P; ++p)
+      s.initial_guess[p] = g[p];
+    float dx = s.und_center_x - s.und_global_center_x;
+    float dy = s.und_center_y - s.und_global_center_y;
+    if (t->cfg.fitting_model != LK_FM_UVUXUYVXVY) {
+      // the reference reads global_initial_guess[2] for fm_U / fm_UV as well (outside their
+      // arrays); taken as 0 here, and nothing is written past the model's own parameters
+      float Vx = P > 2 ? g[2] : 0.f;
+      s.initial_guess[0] += -dy * Vx;
+      if (P > 1)
+        s.initial_guess[1] += dx * Vx;
+    } else {
+      float Ux = g[2], Uy = g[3], Vx = g[4], Vy = g[5];
+      s.initial_guess[0] += dx * Ux + dy * Uy;
+      s.initial_guess[1] += dx * Vx + dy * Vy;
+    }
+    for (int p = 0; p < P; ++p)
+      s.previous_resulting_parameters[p] = s.initial_guess[p];
+  } else {
+    if (t->cfg.deformation == LK_DEF_EULERIAN && t->cfg.reference_image == LK_REF_FIRST) {
+      for (int i = 0; i < P; ++i)
+        s.initial_guess[i] =
+            s.resulting_parameters[i] + (s.resulting_parameters[i] - s.previous_resulting_parameters[i]);
+    } else {
+      for (int i = 0; i < P; ++i)
+        s.initial_guess[i] = s.resulting_parameters[i];
+    }
+    for (int p = 0; p < P; ++p)
+      s.previous_resulting_parameters[p] = s.resulting_parameters[p];
+  }
+  for (int p = 0; p < 6; ++p)
+    guess_out[p] = p < P ? s.initial_guess[p] : 0.f;
+}
+
+static void update_results(lk_tracker *t, lk_frame_result &s, const lk_result &r) { // :2312-2428
+  const int P = t->P;
+  s.chi = r.chi;
+  s.number_of_points = r.numberOfPoints;
+  s.iterations = r.iterations;
+  s.error_code = r.errorCode;
+  s.error_status = r.errorCode != LK_ERROR_NONE;
+  s.und_center_x = r.undCenterX;
+  s.und_center_y = r.undCenterY;
+  for (int p = 0; p < P; ++p)
+    s.resulting_parameters[p] = r.resultingParameters[p];
+  const float *m = s.resulting_parameters;
+  switch (t->cfg.fitting_model) {
+  case LK_FM_UVQ:
+    s.def_angle = m[2] + s.und_angle;
+    break;
+  case LK_FM_UVUXUYVXVY: // best_rotation_UVUxUyVxVy, parameters.cpp:55-58
+    s.def_angle = std::atan2((m[4] - m[3]), (m[2] + m[5] + 2.f)) + s.und_angle;
+    break;
+  default:
+    s.def_angle = 0.f;
+    break;
+  }
+  s.def_e = 0.f;
+  // distortX(x, y, x, y, ...): the model applied to the centre about itself
+  // (interpolation_class.cpp:3-43)
+  const float x = s.und_center_x, y = s.und_center_y, cx = x, cy = y;
+  switch (t->cfg.fitting_model) {
+  case LK_FM_U:
+    s.def_center_x = x + m[0];
+    s.def_center_y = y;
+    break;
+  case LK_FM_UV:
+    s.def_center_x = x + m[0];
+    s.def_center_y = y + m[1];
+    break;
+  case LK_FM_UVQ:
+    s.def_center_x = x + m[0] - (y - cy) * m[2];
+    s.def_center_y = y + m[1] + (x - cx) * m[2];
+    break;
+  default:
+    s.def_center_x = x + m[0] + (x - cx) * m[2] + (y - cy) * m[3];
+    s.def_center_y = y + m[1] + (x - cx) * m[4] + (y - cy) * m[5];
+    break;
+  }
+}
+
+static void update_global_results(lk_tracker *t) { // :2709-2753
+  float average_angle = 0.f, average_center_x = 0.f, average_center_y = 0.f, average_e = 0.f, total_n = 0.f;
+  for (const lk_frame_result &s : t->res) {
+    float n = (float)s.number_of_points;
+    average_angle += s.def_angle * n;
+    average_center_x += s.def_center_x * n;
+    average_center_y += s.def_center_y * n;
+    average_e += s.def_e * n;
+    total_n += n;
+  }
+  average_angle = average_angle / total_n;
+  average_center_x = average_center_x / total_n;
+  average_center_y = average_center_y / total_n;
+  average_e = average_e / total_n;
+  float und_ro = t->res[0].und_global_ro, und_ri = t->res[0].und_global_ri;
+  float def_ri = 1.f + average_e * (und_ro / und_ri - 1.f);
+  for (lk_frame_result &s : t->res) {
+    s.def_global_angle = average_angle;
+    s.def_global_center_x = average_center_x;
+    s.def_global_center_y = average_center_y;
+    s.def_global_e = average_e;
+    s.def_global_ro = s.und_global_ro;
+    s.def_global_ri = def_ri;
+  }
+}
+
+extern "C" {
+
+int lk_tracker_create(const lk_tracker_config *cfg, lk_tracker **out) {
+  if (!cfg || !out)
+    return LK_ERROR_BAD_DOMAIN;
+  *out = nullptr;
+  if (cfg->fitting_model < LK_FM_U || cfg->fitting_model > LK_FM_UVUXUYVXVY || cfg->domain_type < 0 ||
+      cfg->domain_type > 2 || cfg->deformation < 0 || cfg->deformation > 2 || cfg->reference_image < 0 ||
+      cfg->reference_image > 1 || cfg->error_mode < 0 || cfg->error_mode > 2)
+    return LK_ERROR_BAD_DOMAIN;
+  lk_tracker *t = new lk_tracker();
+  t->cfg = *cfg;
+  t->P = n_params(cfg->fitting_model);
+  initialize_report(t);
+  *out = t;
+  return LK_ERROR_NONE;
+}
+
+void lk_tracker_destroy(lk_tracker *t) { delete t; }
+
+const char *lk_tracker_last_error(const lk_tracker *t) { return t ? t->err.c_str() : "null tracker"; }
+
+static void reset_results(lk_tracker *t, int i, int j) {
+  t->results_i = i;
+  t->results_j = j;
+  lk_frame_result z;
+  std::memset(&z, 0, sizeof(z));
+  t->res.assign((size_t)i * (size_t)j, z);
+  t->domain_set = true;
+  t->begun = false;
+}
+
+int lk_tracker_set_rect_domain(lk_tracker *t, float x_begin, float y_begin, float x_end, float y_end,
+                               float x_center, float y_center, int hs, int vs) {
+  if (!t)
+    return LK_ERROR_BAD_DOMAIN;
+  if (t->cfg.domain_type != LK_DOMAIN_RECT || hs < 1 || vs < 1)
+    return t->fail(LK_ERROR_BAD_DOMAIN, "lk_tracker_set_rect_domain: not a rectangular tracker / bad subdivisions");
+  t->x_begin = x_begin, t->y_begin = y_begin, t->x_end = x_end, t->y_end = y_end;
+  t->x_center = x_center, t->y_center = y_center;
+  t->hs = hs, t->vs = vs;
+  reset_results(t, hs, vs);
+  return LK_ERROR_NONE;
+}
+
+int lk_tracker_set_annular_domain(lk_tracker *t, float r_inside, float r_outside, float x_center,
+                                  float y_center, int rs, int as) {
+  if (!t)
+    return LK_ERROR_BAD_DOMAIN;
+  if (t->cfg.domain_type != LK_DOMAIN_ANNULAR || rs < 1 || as < 1)
+    return t->fail(LK_ERROR_BAD_DOMAIN, "lk_tracker_set_annular_domain: not an annular tracker / bad subdivisions");
+  t->r_inside = r_inside, t->r_outside = r_outside, t->x_center = x_center, t->y_center = y_center;
+  t->rs = rs, t->as = as;
+  reset_results(t, rs, as);
+  return LK_ERROR_NONE;
+}
+
+int lk_tracker_set_blob_domain(lk_tracker *t, const float *contour_xy, int n_vertices, float x_center,
+                               float y_center) {
+  if (!t)
+    return LK_ERROR_BAD_DOMAIN;
+  if (t->cfg.domain_type != LK_DOMAIN_BLOB || !contour_xy || n_vertices < 3) // manager_class.cpp:1006,1116-1120
+    return t->fail(LK_ERROR_BAD_DOMAIN, "lk_tracker_set_blob_domain: a blob needs at least 3 contour points");
+  t->contour.assign(contour_xy, contour_xy + 2 * (size_t)n_vertices);
+  t->x_center = x_center, t->y_center = y_center;
+  reset_results(t, 1, 1);
+  return LK_ERROR_NONE;
+}
+
+int lk_tracker_sector_count(const lk_tracker *t) { return t ? (int)t->res.size() : 0; }
+
+int lk_tracker_blob_contour(const lk_tracker *t, const float **contour_xy, int *n_vertices) {
+  if (!t || t->contour.empty())
+    return LK_ERROR_BAD_DOMAIN;
+  if (contour_xy)
+    *contour_xy = t->contour.data();
+  if (n_vertices)
+    *n_vertices = (int)(t->contour.size() / 2);
+  return LK_ERROR_NONE;
+}
+
+int lk_tracker_begin_frame(lk_tracker *t, int frame, lk_sector_command *commands, float *guesses) {
+  if (!t)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!t->domain_set || !commands || !guesses || frame < 0)
+    return t->fail(LK_ERROR_BAD_DOMAIN, "lk_tracker_begin_frame: no domain / null buffers");
+  t->before = t->res;
+  const int S = (int)t->res.size();
+  const bool eulerian = t->cfg.deformation == LK_DEF_EULERIAN;
+  auto later_frames = [&](lk_frame_result &s, lk_sector_command &c) { // manager_class.cpp:354-419
+    if (eulerian) {
+      c.kind = LK_SECTOR_KEEP;
+    } else if (t->cfg.deformation == LK_DEF_STRICT_LAGRANGIAN) {
+      c.kind = LK_SECTOR_REWARP;
+    } else {
+      c.kind = LK_SECTOR_TRANSLATE;
+      c.offset_x = s.und_center_x - s.past_und_center_x;
+      c.offset_y = s.und_center_y - s.past_und_center_y;
+    }
+  };
+  std::memset(commands, 0, sizeof(lk_sector_command) * (size_t)S);
+  switch (t->cfg.domain_type) {
+  case LK_DOMAIN_RECT: { // manager_class.cpp:274-310 + adjust_rectangular_domain :2018-2090
+    lkroi::RectGrid g = lkroi::rect_grid(t->x_begin, t->y_begin, t->x_end, t->y_end, t->hs, t->vs);
+    if (g.xdim < 0 || g.ydim < 0)
+      return t->fail(LK_ERROR_BAD_DOMAIN, "lk_tracker_begin_frame: domain smaller than the grid");
+    for (int i = 0; i < t->hs; ++i)
+      for (int j = 0; j < t->vs; ++j) {
+        const int k = i * t->vs + j;
+        lk_frame_result &s = t->res[(size_t)k];
+        lk_sector_command &c = commands[k];
+        if (frame == 0) {
+          s.und_global_center_x = t->x_center;
+          s.und_global_center_y = t->y_center;
+          s.und_global_angle = 0.f;
+          s.und_global_e = 0.f;
+          s.und_center_x = (float)g.cx[i];
+          s.und_center_y = (float)g.cy[j];
+          s.und_angle = 0.f;
+          s.past_und_center_x = s.und_center_x;
+          s.past_und_center_y = s.und_center_y;
+        } else if (!eulerian) {
+          lagrangian_roll(s, false);
+        }
+        const int center_x = (int)(s.und_center_x + 0.5f), center_y = (int)(s.und_center_y + 0.5f);
+        adjust_initial_guess(t, s, frame, guesses + 6 * (size_t)k);
+        c.use_center = 1;
+        c.center_x = (float)center_x;
+        c.center_y = (float)center_y;
+        if (frame == 0) {
+          c.kind = LK_SECTOR_RECT;
+          c.x0 = center_x - g.xdim, c.y0 = center_y - g.ydim, c.x1 = center_x + g.xdim, c.y1 = center_y + g.ydim;
+        } else {
+          later_frames(s, c);
+        }
+      }
+    break;
+  }
+  case LK_DOMAIN_ANNULAR: { // manager_class.cpp:553-600 + adjust_annular_domain :2092-2237
+    const float ri = t->r_inside, ro = t->r_outside;
+    const float dr = (ro - ri) / (float)t->rs;
+    const float da = 2.f * kPI / (float)t->as;
+    for (int i = 0; i < t->rs; ++i)
+      for (int j = 0; j < t->as; ++j) {
+        const int k = i * t->as + j;
+        lk_frame_result &s = t->res[(size_t)k];
+        lk_sector_command &c = commands[k];
+        if (frame == 0) {
+          s.und_global_center_x = t->x_center;
+          s.und_global_center_y = t->y_center;
+          s.und_global_ro = ro;
+          s.und_global_ri = ri;
+          s.und_global_e = 0.f;
+          s.und_global_angle = 0.f;
+          if (t->as > 1) {
+            float center_angle = 0 + j * da + da / 2.f;
+            float center_r = ri + i * dr + dr / 2.f;
+            s.und_center_x = s.und_global_center_x + center_r * (float)cos((double)center_angle);
+            s.und_center_y = s.und_global_center_y + center_r * (float)sin((double)center_angle);
+          } else {
+            s.und_center_x = s.und_global_center_x;
+            s.und_center_y = s.und_global_center_y;
+          }
+          s.past_und_center_x = s.und_center_x;
+          s.past_und_center_y = s.und_center_y;
+          s.und_e = 0.f;
+          s.und_angle = 0.f;
+        } else if (!eulerian) {
+          lagrangian_roll(s, true);
+        }
+        const float r = ri + i * dr;
+        const float a = s.und_global_angle + j * da;
+        adjust_initial_guess(t, s, frame, guesses + 6 * (size_t)k);
+        c.use_center = 0; // Newton_Raphson(p, n, xy): float mean of the samples (:703-705)
+        if (frame == 0) {
+          c.kind = LK_SECTOR_ANNULAR;
+          c.r = r, c.dr = dr, c.a = a, c.da = da, c.cx = s.und_global_center_x, c.cy = s.und_global_center_y;
+          c.as = t->as;
+        } else {
+          later_frames(s, c);
+        }
+      }
+    break;
+  }
+  default: { // blob: manager_class.cpp:1000-1031 + adjust_blob_domain :2239-2310
+    lk_frame_result &s = t->res[0];
+    lk_sector_command &c = commands[0];
+    if (frame == 0) {
+      s.und_global_center_x = t->x_center;
+      s.und_global_center_y = t->y_center;
+      s.und_global_angle = 0.f;
+      s.und_center_x = t->x_center;
+      s.und_center_y = t->y_center;
+      s.past_und_center_x = s.und_center_x;
+      s.past_und_center_y = s.und_center_y;
+      s.und_angle = 0.f;
+    } else if (!eulerian) {
+      lagrangian_roll(s, false);
+    }
+    adjust_initial_guess(t, s, frame, guesses);
+    c.use_center = 0;
+    if (frame == 0)
+      c.kind = LK_SECTOR_BLOB;
+    else
+      later_frames(s, c);
+    break;
+  }
+  }
+  t->begun = true;
+  return LK_ERROR_NONE;
+}
+
+int lk_tracker_end_frame(lk_tracker *t, int frame, const char *und_name, const char *def_name,
+                         const lk_result *results, int *first_unsolved, int *stop_sequence) {
+  if (!t)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!t->begun || !results)
+    return t->fail(LK_ERROR_BAD_DOMAIN, "lk_tracker_end_frame: lk_tracker_begin_frame has not been called");
+  const int S = (int)t->res.size();
+  const bool stop_mode = t->cfg.error_mode != LK_ERRMODE_CONTINUE;
+  bool error = false;
+  int k = 0;
+  for (; k < S; ++k) { // the sector loop after the solve (manager_class.cpp:452-547)
+    update_results(t, t->res[(size_t)k], results[k]);
+    error = t->res[(size_t)k].error_status != 0; // `error` is overwritten by every sector
+    if (error && stop_mode) {
+      ++k;
+      break;
+    }
+  }
+  for (int u = k; u < S; ++u) // not reached by the reference's loop: as before this frame
+    t->res[(size_t)u] = t->before[(size_t)u];
+  if (first_unsolved)
+    *first_unsolved = k;
+  update_global_results(t);
+  add_frame_to_report(t, frame, und_name ? und_name : "", def_name ? def_name : "");
+  if (stop_sequence) // manager_class.cpp:1485-1486
+    *stop_sequence = error && t->cfg.error_mode == LK_ERRMODE_STOP_ALL;
+  t->begun = false;
+  return LK_ERROR_NONE;
+}
+
+int lk_tracker_get_results(const lk_tracker *t, lk_frame_result *out) {
+  if (!t || !out)
+    return LK_ERROR_BAD_DOMAIN;
+  std::memcpy(out, t->res.data(), t->res.size() * sizeof(lk_frame_result));
+  return LK_ERROR_NONE;
+}
+
+int lk_tracker_report(const lk_tracker *t, char *buf, size_t cap, size_t *needed) {
+  if (!t)
+    return LK_ERROR_BAD_DOMAIN;
+  const std::string s = t->report.str();
+  if (needed)
+    *needed = s.size() + 1;
+  if (buf && cap > 0) {
+    size_t n = s.size() < cap - 1 ? s.size() : cap - 1;
+    std::memcpy(buf, s.data(), n);
+    buf[n] = 0;
+  }
+  return LK_ERROR_NONE;
+}
+
+// ------------------------------------------------------------------------------------
+// frame loop on an engine
+// ------------------------------------------------------------------------------------
+int lk_sequence_frame(lk_engine *e, lk_tracker *t, int frame, const char *und_name, const char *def_name,
+                      int *stop_sequence) {
+  if (!e || !t)
+    return LK_ERROR_BAD_DOMAIN;
+  const int S = lk_tracker_sector_count(t);
+  std::vector<lk_sector_command> cmds((size_t)S);
+  std::vector<float> guesses(6 * (size_t)S);
+  int rc = lk_tracker_begin_frame(t, frame, cmds.data(), guesses.data());
+  if (rc)
+    return rc;
+  if (frame == 0) {
+    rc = lk_clear_sectors(e);
+    for (int s = 0; s < S && !rc; ++s) {
+      const lk_sector_command &c = cmds[(size_t)s];
+      switch (c.kind) {
+      case LK_SECTOR_RECT: rc = lk_set_sector_rect(e, s, c.x0, c.y0, c.x1, c.y1); break;
+      case LK_SECTOR_ANNULAR: rc = lk_set_sector_annular(e, s, c.r, c.dr, c.a, c.da, c.cx, c.cy, c.as); break;
+      case LK_SECTOR_BLOB: {
+        const float *xy = nullptr;
+        int n = 0;
+        rc = lk_tracker_blob_contour(t, &xy, &n);
+        if (!rc)
+          rc = lk_set_sector_blob(e, s, xy, n);
+        break;
+      }
+      default: rc = LK_ERROR_BAD_DOMAIN; break;
+      }
+    }
+    if (!rc)
+      rc = lk_commit_sectors(e);
+  } else if (S > 0 && cmds[0].kind != LK_SECTOR_KEEP) {
+    std::vector<float> off(2 * (size_t)S), cen(2 * (size_t)S);
+    for (int s = 0; s < S; ++s) {
+      off[2 * (size_t)s] = cmds[(size_t)s].offset_x;
+      off[2 * (size_t)s + 1] = cmds[(size_t)s].offset_y;
+      cen[2 * (size_t)s] = cmds[(size_t)s].center_x;
+      cen[2 * (size_t)s + 1] = cmds[(size_t)s].center_y;
+    }
+    const float *centers = cmds[0].use_center ? cen.data() : nullptr;
+    rc = cmds[0].kind == LK_SECTOR_TRANSLATE ? lk_translate_sectors(e, off.data(), centers)
+                                             : lk_rewarp_sectors(e, centers);
+  }
+  if (rc)
+    return rc;
+  std::vector<lk_result> results((size_t)S);
+  rc = lk_correlate_all(e, guesses.data(), results.data());
+  if (rc)
+    return rc;
+  int first_unsolved = S;
+  rc = lk_tracker_end_frame(t, frame, und_name, def_name, results.data(), &first_unsolved, stop_sequence);
+  if (!rc && first_unsolved < S && frame > 0)
+    rc = lk_restore_sectors(e, first_unsolved); // their samples stay where the previous frame left them
+  return rc;
+}
+
+int lk_sequence_run(lk_engine *e, lk_tracker *t, int n_frames, lk_frame_provider provider, void *user,
+                    int *pairs_done) {
+  if (pairs_done)
+    *pairs_done = 0;
+  if (!e || !t || !provider || n_frames < 2)
+    return LK_ERROR_BAD_DOMAIN;
+  struct Frame {
+    const uint8_t *px = nullptr;
+    int rows = 0, cols = 0, step = 0;
+    std::string name;
+  };
+  auto fetch = [&](int index) {
+    Frame f;
+    const char *name = nullptr;
+    f.px = provider(user, index, &f.rows, &f.cols, &f.step, &name);
+    f.name = name ? name : ("frame" + std::to_string(index));
+    return f;
+  };
+  Frame f0 = fetch(0), f1 = fetch(1);
+  if (!f0.px || !f1.px)
+    return LK_ERROR_BAD_DOMAIN;
+  int rc = lk_set_image(e, LK_IMG_UND, f0.px, f0.rows, f0.cols, f0.step);
+  if (!rc)
+    rc = lk_set_image(e, LK_IMG_DEF, f1.px, f1.rows, f1.cols, f1.step);
+  std::string und_name = f0.name, def_name = f1.name;
+  const int pairs = n_frames - 1;
+  for (int k = 0; k < pairs && !rc; ++k) {
+    // load and upload frame k + 2 while pair k is being solved (manager_class.cpp:1438-1447:
+    // std::async + set_next_image; here the upload and pyramid build run on the engine's
+    // next-frame stream)
+    std::future<int> next;
+    Frame fn;
+    const bool have_next = k + 2 < n_frames;
+    if (have_next)
+      next = std::async(std::launch::async, [&, k] {
+        fn = fetch(k + 2);
+        return fn.px ? lk_set_image(e, LK_IMG_NXT, fn.px, fn.rows, fn.cols, fn.step) : (int)LK_ERROR_BAD_DOMAIN;
+      });
+    int stop = 0;
+    rc = lk_sequence_frame(e, t, k, und_name.c_str(), def_name.c_str(), &stop);
+    int nrc = have_next ? next.get() : 0;
+    if (!rc && pairs_done)
+      *pairs_done = k + 1;
+    if (rc || stop)
+      break;
+    if (have_next) {
+      if (nrc) // error_multiThread in the reference (manager_class.cpp:1470-1475)
+        return nrc;
+      // image roles of the next pair (manager_class.cpp:1386-1407, :166-243)
+      if (t->cfg.reference_image == LK_REF_PREVIOUS) {
+        rc = lk_rotate_und_from_def(e);
+        und_name = def_name;
+      }
+      if (!rc)
+        rc = lk_rotate_def_from_nxt(e);
+      def_name = fn.name;
+    }
+  }
+  return rc;
+}
+
+int lk_load_pgm(const char *path, uint8_t **pixels, int *rows, int *cols) {
+  if (!path || !pixels || !rows || !cols)
+    return LK_ERROR_BAD_DOMAIN;
+  *pixels = nullptr;
+  FILE *f = std::fopen(path, "rb");
+  if (!f)
+    return LK_ERROR_BAD_DOMAIN;
+  auto token = [&](int &v) { // whitespace / comment separated decimal
+    int c = std::fgetc(f);
+    for (;;) {
+      while (c == ' ' || c == '\t' || c == '\n' || c == '\r')
+        c = std::fgetc(f);
+      if (c != '#')
+        break;
+      while (c != '\n' && c != EOF)
+        c = std::fgetc(f);
+    }
+    if (c < '0' || c > '9')
+      return false;
+    long acc = 0;
+    while (c >= '0' && c <= '9') {
+      acc = acc * 10 + (c - '0');
+      if (acc > 1 << 30)
+        return false;
+      c = std::fgetc(f);
+    }
+    v = (int)acc; // the single whitespace after the token has been consumed
+    return true;
+  };
+  int w = 0, h = 0, maxval = 0;
+  bool ok = std::fgetc(f) == 'P' && std::fgetc(f) == '5' && token(w) && token(h) && token(maxval) && w > 0 &&
+            h > 0 && maxval > 0 && maxval <= 255;
+  uint8_t *buf = nullptr;
+  if (ok) {
+    buf = (uint8_t *)std::malloc((size_t)w * (size_t)h);
+    ok = buf && std::fread(buf, 1, (size_t)w * (size_t)h, f) == (size_t)w * (size_t)h;
+  }
+  std::fclose(f);
+  if (!ok) {
+    std::free(buf);
+    return LK_ERROR_BAD_DOMAIN;
+  }
+  *pixels = buf;
+  *rows = h;
+  *cols = w;
+  return LK_ERROR_NONE;
+}
+
+void lk_free_image(uint8_t *pixels) { std::free(pixels); }
+
+} // extern "C"

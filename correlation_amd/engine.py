@@ -140,6 +140,22 @@ class HipCorrelationEngine:
     def commit_sectors(self):
         self._chk(self.lib.lk_commit_sectors(self._h))
 
+    def translate_sectors(self, offsets, centers=None):
+        """Lagrangian description: move every sector's samples by add_pair(offset)."""
+        o = np.ascontiguousarray(offsets, np.float32).reshape(-1, 2)
+        c = None if centers is None else np.ascontiguousarray(centers, np.float32).reshape(-1, 2)
+        self._chk(self.lib.lk_translate_sectors(self._h, _ffi.fptr(o), None if c is None else _ffi.fptr(c)))
+
+    def rewarp_sectors(self, centers=None):
+        """Strict Lagrangian description: und samples <- def samples of the last solve."""
+        c = None if centers is None else np.ascontiguousarray(centers, np.float32).reshape(-1, 2)
+        self._chk(self.lib.lk_rewarp_sectors(self._h, None if c is None else _ffi.fptr(c)))
+
+    def last_evaluated_parameters(self):
+        out = np.zeros((self.n_sectors, 6), np.float32)
+        self._chk(self.lib.lk_get_last_evaluated_parameters(self._h, _ffi.fptr(out)))
+        return out
+
     @property
     def n_sectors(self):
         return self.lib.lk_sector_count(self._h)

@@ -152,6 +152,23 @@ int lk_set_sector_points(lk_engine *e, int sector, const float *xy, int n, int u
 /* build per-level sample lists (pyramid_class.cpp:289-362) and upload; must be called
  * after the lk_set_sector_* calls and before lk_correlate_* */
 int lk_commit_sectors(lk_engine *e);
+/* Domain tracking between the frames of a sequence, CPU-engine semantics (the CUDA engine's
+ * cudaPolygon::updatePolygon, cuda_polygon.cu:268-415, moves by its own lastGood
+ * parameters instead).  Both keep the per-sector sequence state (guess history).
+ *  - Lagrangian (manager_class.cpp:381-419): sample (x,y) -> ((int)(ox+x+0.5f), (int)(oy+y+0.5f))
+ *    with the sector's offset (ox,oy) = new und centre - past und centre (add_pair, :38-47);
+ *  - strict Lagrangian (manager_class.cpp:369-380): the deformed sample positions of the last
+ *    solve (CorrelationClass::getDefXY0, correlation_class.cpp:884-896: warped with the
+ *    parameters of the last level-0 evaluation) become the undeformed samples.
+ * offsets_xy [S][2]; centers_xy [S][2] = centres for the next solve (the rectangular path
+ * passes integers, manager_class.cpp:438-441) or NULL = float mean of the new samples. */
+int lk_translate_sectors(lk_engine *e, const float *offsets_xy, const float *centers_xy);
+int lk_rewarp_sectors(lk_engine *e, const float *centers_xy);
+/* undo the last lk_translate_sectors / lk_rewarp_sectors for sectors >= first_sector: the
+ * sectors a frame never reached because it stopped at an error (manager_class.cpp:520-546) */
+int lk_restore_sectors(lk_engine *e, int first_sector);
+/* [S][6]: the parameters the last evaluation of each sector ran at (level-0 scale) */
+int lk_get_last_evaluated_parameters(lk_engine *e, float *out);
 int lk_sector_count(const lk_engine *e);
 /* CorrelationClass::get_number_of_points / get_und_x/y_center (correlation_class.cpp:850-868) */
 int lk_get_sector_info(lk_engine *e, int sector, int *n_points, float *cx, float *cy);

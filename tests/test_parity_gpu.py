@@ -664,3 +664,85 @@ def test_solo_half_wavefronts(oracle, speckle512, monkeypatch):
     assert inv_one.tobytes() == inv[3].tobytes()
     shard, _, _ = run(True, 37, 51)      # odd start: every sector has a different partner
     assert shard.tobytes() == inv[37:88].tobytes()
+
+
+# ---------------------------------------------------------------------------------------------
+# sequences: lk_sequence_run (engine + tracker, include/lk_tracker.h) against the manager oracle
+# ---------------------------------------------------------------------------------------------
+def _report_table(text):
+    rows = [r.split(",") for r in text.strip().split("\n")]
+    head, body = rows[0], rows[1:]
+    return head, body
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("domain,deformation,reference,model", [
+    (0, 2, 0, ca.FM_UVUXUYVXVY),    # rectangular grid, Eulerian, first image as reference (config 4's mode)
+    (0, 1, 1, ca.FM_UVUXUYVXVY),    # rectangular, Lagrangian, previous image as reference
+    (0, 0, 1, ca.FM_UV),            # rectangular, strict Lagrangian
+    (1, 1, 1, ca.FM_UVQ),           # annular, Lagrangian
+    (1, 0, 1, ca.FM_UVUXUYVXVY),    # annular, strict Lagrangian
+    (2, 2, 0, ca.FM_UVUXUYVXVY),    # blob, Eulerian
+    (2, 1, 1, ca.FM_UVUXUYVXVY),    # blob, Lagrangian
+])
+def test_sequence_tracking_against_manager_oracle(oracle, domain, deformation, reference, model):
+    """perform_multiframe_correlation on the HIP engine: frame roles (und <- def <- nxt with the
+    next frame uploaded behind the solve), sector tracking, guesses, frame_results and the CSV
+    report, compared with the CPU restatement of managerClass driving the CPU oracle."""
+    from correlation_amd import tracker as tk
+    from oracle import lk_manager_oracle as mo
+    frames = ca.speckle.speckle_sequence(256, 256, 5, velocity=(0.9, -0.5), dilation=4e-4, seed=3)
+    names = [f"f{i}.pgm" for i in range(len(frames))]
+    guess = [0.5, -0.25, 0.0, 0.0, 0.0, 0.0]
+    e = ca.HipCorrelationEngine(fitting_model=model)
+    t = tk.SequenceTracker(model, domain, deformation, reference, tk.ERRMODE_CONTINUE, guess, lib=e.lib)
+    o = oracle.Oracle(model=model)
+    o.set_image(0, frames[0])
+    o.set_image(1, frames[1])
+    m = mo.ManagerOracle(o, model, domain, deformation, reference, mo.ERRMODE_CONTINUE, guess)
+    if domain == 0:
+        args = (40.0, 44.0, 215.0, 211.0, 127.5, 127.5, 4, 3)
+        t.set_rect_domain(*args), m.set_rect_domain(*args)
+    elif domain == 1:
+        args = (30.0, 78.0, 128.0, 126.0, 2, 3)
+        t.set_annular_domain(*args), m.set_annular_domain(*args)
+    else:
+        ang = 2 * np.pi * np.arange(7) / 7
+        contour = np.stack([128 + 45 * np.cos(ang), 126 + 38 * np.sin(ang)], 1).astype(np.float32)
+        t.set_blob_domain(contour, 128.0, 126.0), m.set_blob_domain(contour, 128.0, 126.0)
+    assert tk.run_sequence(e, t, frames, names) == len(frames) - 1
+    for k in range(len(frames) - 1):
+        if k > 0:
+            if reference == 1:
+                o.und_from_def()
+            o.set_image(2, frames[k + 1])
+            o.def_from_nxt()
+        m.run_frame(k, names[0] if reference == 0 else names[k], names[k + 1])
+    head_g, got = _report_table(t.report())
+    head_w, want = _report_table(m.report_text())
+    assert head_g == head_w and len(got) == len(want) == (len(frames) - 1) * t.n_sectors
+    col = {name: i for i, name in enumerate(head_g)}
+    P = ca.N_PARAMS[model]
+    strict_lagrangian = deformation == 0
+    same_it = 0
+    for rg, rw in zip(got, want):
+        assert rg[:3] == rw[:3]                                   # frame number and file names
+        for name in ("number_of_points", "error_status", "error_code"):
+            assert rg[col[name]] == rw[col[name]], (rg[0], name)
+        same_it += abs(int(rg[col["iterations"]]) - int(rw[col["iterations"]])) <= 1
+        tol_c = 2e-2 if strict_lagrangian else 5e-3                 # float sample lists drift a little
+        for name in ("und_center_x", "und_center_y", "def_center_x", "def_center_y", "und_global_center_x",
+                     "def_global_center_x", "def_global_center_y", "parameter_0", "Initial_guess_0"):
+            assert abs(float(rg[col[name]]) - float(rw[col[name]])) <= tol_c, (rg[0], name, rg[col[name]], rw[col[name]])
+        for p in range(2, P):
+            assert abs(float(rg[col[f"parameter_{p}"]]) - float(rw[col[f"parameter_{p}"]])) <= 2e-4
+        assert abs(float(rg[col["def_angle(rad)"]]) - float(rw[col["def_angle(rad)"]])) <= 2e-4
+        cg, cw = float(rg[col["chi"]]), float(rw[col["chi"]])
+        assert abs(cg - cw) <= 2e-2 * abs(cw) + 1e-6
+    assert same_it >= 0.9 * len(got)
+    # the tracked displacement is the ground truth of the sequence: 0.9 / -0.5 px per frame
+    last = got[-t.n_sectors:]
+    if reference == 0 and deformation == 2:
+        u = np.array([float(r[col["parameter_0"]]) for r in last])
+        assert np.abs(u - 0.9 * (len(frames) - 1)).max() < 0.25
+    e.close(), t.close()
