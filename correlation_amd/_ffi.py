@@ -75,6 +75,7 @@ SYMBOLS = {
     "lk_translate_sectors": (C.c_int, [_P, _F, _F]),
     "lk_rewarp_sectors": (C.c_int, [_P, _F]),
     "lk_restore_sectors": (C.c_int, [_P, C.c_int]),
+    "lk_update_sector": (C.c_int, [_P, C.c_int, C.c_int]),
     "lk_get_last_evaluated_parameters": (C.c_int, [_P, _F]),
     "lk_sector_count": (C.c_int, [_P]),
     "lk_get_sector_info": (C.c_int, [_P, C.c_int, _I, _F, _F]),

@@ -62,6 +62,7 @@ struct HostSector {
   bool is_rect = false;
   int x0 = 0, y0 = 0, x1 = -1, y1 = -1; // inclusive rectangle (is_rect)
   float cx = 0.f, cy = 0.f;
+  bool has_center = false; // the solve centre was given (rectangular path) rather than the samples' mean
   bool set = false;
   int n0() const { return is_rect ? (x1 - x0 + 1) * (y1 - y0 + 1) : (int)(xy.size() / 2); }
   std::vector<float> points() const { // level-0 list in the CPU engine's order
@@ -134,6 +135,7 @@ struct lk_engine {
   std::vector<HostSector> hs; // staging until commit
   std::vector<HostSector> hs_backup; // the lists before the last lk_translate / lk_rewarp_sectors
   bool committed = false;
+  bool recommit_pending = false; // lk_update_sector moved sample lists: rebuild before the next solve
   int S = 0;
   std::vector<uint32_t> h_off[LK_MAX_LEVELS];
   DevBuf<float2> d_xy[LK_MAX_LEVELS];
@@ -471,6 +473,7 @@ int lk_set_sector_rect(lk_engine *e, int sector, int x0, int y0, int x1, int y1)
   s->y1 = y1;
   s->cx = (float)(x0 + x1) * 0.5f;
   s->cy = (float)(y0 + y1) * 0.5f;
+  s->has_center = true;
   s->set = true;
   return LK_ERROR_NONE;
 }
@@ -503,6 +506,7 @@ int lk_set_rect_grid(lk_engine *e, float x_begin, float y_begin, float x_end, fl
     s.y1 = cy + g.ydim;
     s.cx = (float)cx; // manager_class.cpp:438-441 passes the integer centre
     s.cy = (float)cy;
+    s.has_center = true;
     s.set = true;
   }
   return LK_ERROR_NONE;
@@ -520,6 +524,7 @@ int lk_set_sector_annular(lk_engine *e, int sector, float r, float dr, float a, 
   if (!lkroi::annular_points(r, dr, a, da, cx, cy, as, s->xy) || s->xy.empty())
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sector_annular: empty sector");
   lkroi::mean_center(s->xy.data(), (int)(s->xy.size() / 2), s->cx, s->cy); // correlation_class.cpp:337-339
+  s->has_center = false;
   s->set = true;
   return LK_ERROR_NONE;
 }
@@ -537,6 +542,7 @@ int lk_set_sector_blob(lk_engine *e, int sector, const float *contour_xy, int n_
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sector_blob: contour is not a simple polygon");
   }
   lkroi::mean_center(s->xy.data(), (int)(s->xy.size() / 2), s->cx, s->cy);
+  s->has_center = false;
   s->set = true;
   return LK_ERROR_NONE;
 }
@@ -556,6 +562,7 @@ int lk_set_sector_points(lk_engine *e, int sector, const float *xy, int n, int u
   } else {
     lkroi::mean_center(xy, n, s->cx, s->cy);
   }
+  s->has_center = use_center != 0;
   s->set = true;
   return LK_ERROR_NONE;
 }
@@ -749,45 +756,68 @@ int lk_commit_sectors(lk_engine *e) {
 // the sector moves by add_pair(offset), i.e. (int)(offset + v + 0.5f) per coordinate
 // (manager_class.cpp:38-47).  A rectangle whose columns and rows all move by one integer
 // stays an implicit rectangle; otherwise the sector becomes an explicit list.
+static void translate_one(HostSector &h, float ox, float oy, const float *center) {
+  if (h.is_rect) {
+    const int sx = (int)lkroi::add_pair_round(ox, (float)h.x0) - h.x0;
+    const int sy = (int)lkroi::add_pair_round(oy, (float)h.y0) - h.y0;
+    bool uniform = true;
+    for (int x = h.x0; x <= h.x1 && uniform; ++x)
+      uniform = (int)lkroi::add_pair_round(ox, (float)x) - x == sx;
+    for (int y = h.y0; y <= h.y1 && uniform; ++y)
+      uniform = (int)lkroi::add_pair_round(oy, (float)y) - y == sy;
+    if (uniform) {
+      h.x0 += sx, h.x1 += sx, h.y0 += sy, h.y1 += sy;
+    } else {
+      h.xy = h.points();
+      h.is_rect = false;
+    }
+  }
+  if (!h.is_rect) {
+    const size_t n = h.xy.size() / 2;
+    for (size_t i = 0; i < n; ++i) {
+      h.xy[2 * i] = lkroi::add_pair_round(ox, h.xy[2 * i]);
+      h.xy[2 * i + 1] = lkroi::add_pair_round(oy, h.xy[2 * i + 1]);
+    }
+  }
+  if (center) {
+    h.cx = center[0];
+    h.cy = center[1];
+  } else { // Newton_Raphson(p, n, xy): float mean of the samples (pyramid_class.cpp:325-340)
+    const std::vector<float> pts = h.points();
+    lkroi::mean_center(pts.data(), (int)(pts.size() / 2), h.cx, h.cy);
+  }
+}
+
+static void rewarp_one(HostSector &h, int model, const float *p, const float *center) {
+  if (h.is_rect) {
+    h.xy = h.points();
+    h.is_rect = false;
+  }
+  const size_t n = h.xy.size() / 2;
+  const float cx = h.cx, cy = h.cy;
+  for (size_t i = 0; i < n; ++i) {
+    float xd, yd;
+    lkroi::warp_point(model, h.xy[2 * i], h.xy[2 * i + 1], cx, cy, p, xd, yd);
+    h.xy[2 * i] = xd;
+    h.xy[2 * i + 1] = yd;
+  }
+  if (center) {
+    h.cx = center[0];
+    h.cy = center[1];
+  } else {
+    lkroi::mean_center(h.xy.data(), (int)n, h.cx, h.cy);
+  }
+}
+
 int lk_translate_sectors(lk_engine *e, const float *offsets_xy, const float *centers_xy) {
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
   if (!e->committed || !offsets_xy)
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_translate_sectors: sectors are not committed");
   e->hs_backup = e->hs;
-  for (int s = 0; s < e->S; ++s) {
-    HostSector &h = e->hs[(size_t)s];
-    const float ox = offsets_xy[2 * (size_t)s], oy = offsets_xy[2 * (size_t)s + 1];
-    if (h.is_rect) {
-      const int sx = (int)lkroi::add_pair_round(ox, (float)h.x0) - h.x0;
-      const int sy = (int)lkroi::add_pair_round(oy, (float)h.y0) - h.y0;
-      bool uniform = true;
-      for (int x = h.x0; x <= h.x1 && uniform; ++x)
-        uniform = (int)lkroi::add_pair_round(ox, (float)x) - x == sx;
-      for (int y = h.y0; y <= h.y1 && uniform; ++y)
-        uniform = (int)lkroi::add_pair_round(oy, (float)y) - y == sy;
-      if (uniform) {
-        h.x0 += sx, h.x1 += sx, h.y0 += sy, h.y1 += sy;
-      } else {
-        h.xy = h.points();
-        h.is_rect = false;
-      }
-    }
-    if (!h.is_rect) {
-      const size_t n = h.xy.size() / 2;
-      for (size_t i = 0; i < n; ++i) {
-        h.xy[2 * i] = lkroi::add_pair_round(ox, h.xy[2 * i]);
-        h.xy[2 * i + 1] = lkroi::add_pair_round(oy, h.xy[2 * i + 1]);
-      }
-    }
-    if (centers_xy) {
-      h.cx = centers_xy[2 * (size_t)s];
-      h.cy = centers_xy[2 * (size_t)s + 1];
-    } else { // Newton_Raphson(p, n, xy): float mean of the samples (pyramid_class.cpp:325-340)
-      const std::vector<float> pts = h.points();
-      lkroi::mean_center(pts.data(), (int)(pts.size() / 2), h.cx, h.cy);
-    }
-  }
+  for (int s = 0; s < e->S; ++s)
+    translate_one(e->hs[(size_t)s], offsets_xy[2 * (size_t)s], offsets_xy[2 * (size_t)s + 1],
+                  centers_xy ? centers_xy + 2 * (size_t)s : nullptr);
   return commit_impl(e, true);
 }
 
@@ -805,29 +835,39 @@ int lk_rewarp_sectors(lk_engine *e, const float *centers_xy) {
   HIPCHK(hipMemcpyAsync(ev.data(), e->d_last_eval_p.p, ev.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   e->hs_backup = e->hs;
-  for (int s = 0; s < e->S; ++s) {
-    HostSector &h = e->hs[(size_t)s];
-    if (h.is_rect) {
-      h.xy = h.points();
-      h.is_rect = false;
-    }
-    const size_t n = h.xy.size() / 2;
-    const float *p = &ev[6 * (size_t)s];
-    const float cx = h.cx, cy = h.cy;
-    for (size_t i = 0; i < n; ++i) {
-      float xd, yd;
-      lkroi::warp_point(e->cfg.fitting_model, h.xy[2 * i], h.xy[2 * i + 1], cx, cy, p, xd, yd);
-      h.xy[2 * i] = xd;
-      h.xy[2 * i + 1] = yd;
-    }
-    if (centers_xy) {
-      h.cx = centers_xy[2 * (size_t)s];
-      h.cy = centers_xy[2 * (size_t)s + 1];
-    } else {
-      lkroi::mean_center(h.xy.data(), (int)n, h.cx, h.cy);
-    }
-  }
+  for (int s = 0; s < e->S; ++s)
+    rewarp_one(e->hs[(size_t)s], e->cfg.fitting_model, &ev[6 * (size_t)s],
+               centers_xy ? centers_xy + 2 * (size_t)s : nullptr);
   return commit_impl(e, true);
+}
+
+// cudaPolygon::updatePolygon's call shape (cuda_class.cu:569, one sector, the engine's own
+// last record of it) with the CPU engine's meaning: the sector moves to where update_results
+// (manager_class.cpp:2406-2411) puts its centre, c + (u, v).  The re-commit is deferred to
+// the next solve.  mode: deformationDescriptionEnum (0 strict Lagrangian, 1 Lagrangian, 2 Eulerian).
+int lk_update_sector(lk_engine *e, int sector, int mode) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!e->committed || sector < 0 || sector >= e->S || mode < 0 || mode > 2)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_update_sector: unknown sector / mode");
+  if (mode == 2)
+    return LK_ERROR_NONE;
+  HIPCHK(hipSetDevice(e->cfg.device));
+  lk_result r;
+  float ev[6];
+  HIPCHK(hipMemcpyAsync(&r, e->d_result.p + sector, sizeof(r), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(ev, e->d_last_eval_p.p + 6 * (size_t)sector, sizeof(ev), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HostSector &h = e->hs[(size_t)sector];
+  const float *m = r.resultingParameters;
+  const float def_cx = h.cx + m[0], def_cy = e->P > 1 ? h.cy + m[1] : h.cy; // interpolation_class.cpp:3-43
+  const float center[2] = {(float)(int)(def_cx + 0.5f), (float)(int)(def_cy + 0.5f)}; // manager_class.cpp:2087-2088
+  if (mode == 1)
+    translate_one(h, def_cx - h.cx, def_cy - h.cy, h.has_center ? center : nullptr);
+  else
+    rewarp_one(h, e->cfg.fitting_model, ev, h.has_center ? center : nullptr);
+  e->recommit_pending = true;
+  return LK_ERROR_NONE;
 }
 
 // Sectors the manager's loop never reached on a frame that stopped at an error
@@ -933,6 +973,12 @@ int lk_get_def_xy(lk_engine *e, int sector, const float *p, float *xy, int cap, 
 static int refresh_level_views(lk_engine *e) {
   if (!e->committed)
     return e->fail(LK_ERROR_BAD_DOMAIN, "sectors are not committed (call lk_commit_sectors)");
+  if (e->recommit_pending) {
+    e->recommit_pending = false;
+    int rc = commit_impl(e, true);
+    if (rc)
+      return rc;
+  }
   const DevImage &u = e->img[LK_IMG_UND], &d = e->img[LK_IMG_DEF];
   if (!u.valid || !d.valid)
     return e->fail(LK_ERROR_BAD_DOMAIN, "undeformed and deformed images must be set before correlating");

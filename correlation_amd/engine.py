@@ -151,6 +151,13 @@ class HipCorrelationEngine:
         c = None if centers is None else np.ascontiguousarray(centers, np.float32).reshape(-1, 2)
         self._chk(self.lib.lk_rewarp_sectors(self._h, None if c is None else _ffi.fptr(c)))
 
+    def update_sector(self, sector, mode):
+        """CudaClass::updatePolygon(iSector, deformationDescription), CPU-manager semantics."""
+        self._chk(self.lib.lk_update_sector(self._h, sector, mode))
+
+    def restore_sectors(self, first_sector):
+        self._chk(self.lib.lk_restore_sectors(self._h, first_sector))
+
     def last_evaluated_parameters(self):
         out = np.zeros((self.n_sectors, 6), np.float32)
         self._chk(self.lib.lk_get_last_evaluated_parameters(self._h, _ffi.fptr(out)))

@@ -177,9 +177,14 @@ public:
     sectors_dirty_ = true;
     return (errorEnum)lk_set_sector_blob(engine_, 0, c.data(), (int)blobContour.size());
   }
-  // Lagrangian domain updates (cuda_polygon.cu:268-415) are a "next" row of the scope
-  // table: re-register the moved sector with resetPolygon / lk_set_sector_points.
-  void updatePolygon(int /*iSector*/, deformationDescriptionEnum /*deformationDescription*/) {}
+  // Lagrangian domain updates (cuda_polygon.cu:268-415), CPU-manager semantics
+  // (manager_class.cpp:354-419): the sector follows its own last record.  One sector per
+  // call rebuilds the engine's lists before the next solve; whole frames go through
+  // lk_sequence_frame / lk_translate_sectors / lk_rewarp_sectors (include/lk_tracker.h).
+  void updatePolygon(int iSector, deformationDescriptionEnum deformationDescription) {
+    if (ensure_engine() && commit())
+      lk_update_sector(engine_, iSector, (int)deformationDescription);
+  }
 
   CorrelationResult *correlate(int iSector, float *initial_guess_, frame_results & /*results*/) {
     lk_result r{};

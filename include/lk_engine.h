@@ -164,6 +164,11 @@ int lk_commit_sectors(lk_engine *e);
  * passes integers, manager_class.cpp:438-441) or NULL = float mean of the new samples. */
 int lk_translate_sectors(lk_engine *e, const float *offsets_xy, const float *centers_xy);
 int lk_rewarp_sectors(lk_engine *e, const float *centers_xy);
+/* one sector, from the engine's own last record of it - the call shape of
+ * CudaClass::updatePolygon(iSector, deformationDescription) (cuda_class.cu:569) with the CPU
+ * manager's meaning; mode = deformationDescriptionEnum (0 strict Lagrangian, 1 Lagrangian,
+ * 2 Eulerian = nothing).  The lists are rebuilt before the next solve. */
+int lk_update_sector(lk_engine *e, int sector, int mode);
 /* undo the last lk_translate_sectors / lk_rewarp_sectors for sectors >= first_sector: the
  * sectors a frame never reached because it stopped at an error (manager_class.cpp:520-546) */
 int lk_restore_sectors(lk_engine *e, int first_sector);

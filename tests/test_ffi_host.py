@@ -1,5 +1,5 @@
 """CPU-side checks of the product boundary: the C-ABI library builds for gfx950, loads,
-exports every symbol include/lk_engine.h declares, and refuses to run without a HIP
+exports every symbol include/lk_engine.h and include/lk_tracker.h declare, and refuses to run without a HIP
 device (no CPU fallback)."""
 import ctypes as C
 import os
@@ -15,16 +15,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_functions():
-    hdr = open(os.path.join(ROOT, "include", "lk_engine.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(lk_[a-z_0-9]+)\s*\(", hdr)))
+    names = set()
+    for header in ("lk_engine.h", "lk_tracker.h"):
+        hdr = open(os.path.join(ROOT, "include", header)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        hdr = re.sub(r"typedef[^;]*\(\*lk_[a-z_0-9]+\)[^;]*;", "", hdr)      # function-pointer typedefs
+        names |= set(re.findall(r"\b(lk_[a-z_0-9]+)\s*\(", hdr))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol(engine_lib):
     names = declared_functions()
     assert len(names) >= 30
     for n in names:
-        assert hasattr(engine_lib, n), f"{n} declared in lk_engine.h but not exported"
+        assert hasattr(engine_lib, n), f"{n} declared in include/*.h but not exported"
         assert n in _ffi.SYMBOLS, f"{n} has no ctypes prototype"
     assert sorted(_ffi.SYMBOLS) == names
 

@@ -746,3 +746,50 @@ def test_sequence_tracking_against_manager_oracle(oracle, domain, deformation, r
         u = np.array([float(r[col["parameter_0"]]) for r in last])
         assert np.abs(u - 0.9 * (len(frames) - 1)).max() < 0.25
     e.close(), t.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])
+def test_update_sector_equals_the_frame_loop(mode):
+    """CudaClass::updatePolygon's call shape (one sector, the engine's own last record) must move
+    a sector exactly like the tracker-driven frame loop does (strict Lagrangian 0, Lagrangian 1)."""
+    from correlation_amd import tracker as tk
+    frames = ca.speckle.speckle_sequence(256, 256, 3, velocity=(1.1, -0.6), dilation=3e-4, seed=5)
+    model = ca.FM_UVUXUYVXVY
+
+    def setup():
+        e = ca.HipCorrelationEngine(fitting_model=model)
+        e.set_undeformed_image(frames[0])
+        e.set_deformed_image(frames[1])
+        return e
+
+    # A: the frame loop
+    ea = setup()
+    t = tk.SequenceTracker(model, tk.DOMAIN_RECT, mode, tk.REF_PREVIOUS, lib=ea.lib)
+    t.set_rect_domain(40.0, 44.0, 215.0, 211.0, 127.5, 127.5, 3, 3)
+    tk.sequence_frame(ea, t, 0)
+    first = t.results()
+    ea.makeUndPyramidFromDef()
+    ea.set_deformed_image(frames[2])
+    tk.sequence_frame(ea, t, 1)
+    want = t.results()
+    # B: per-sector calls
+    eb = setup()
+    cmds, guesses = tk.SequenceTracker(model, tk.DOMAIN_RECT, mode, tk.REF_PREVIOUS, lib=eb.lib), None
+    cmds.set_rect_domain(40.0, 44.0, 215.0, 211.0, 127.5, 127.5, 3, 3)
+    c0, g0 = cmds.begin_frame(0)
+    for s, c in enumerate(c0):
+        eb.resetPolygon_rect(s, int(c["x0"]), int(c["y0"]), int(c["x1"]), int(c["y1"]))
+    eb.commit_sectors()
+    r0 = eb.correlate_all(g0)
+    assert np.array_equal(r0["p"], first["resulting_parameters"])
+    eb.makeUndPyramidFromDef()
+    eb.set_deformed_image(frames[2])
+    for s in range(len(c0)):
+        eb.update_sector(s, mode)
+    r1 = eb.correlate_all(r0["p"])
+    assert np.array_equal(r1["und_cx"], want["und_center_x"]) and np.array_equal(r1["und_cy"], want["und_center_y"])
+    assert np.array_equal(r1["n_points"], want["number_of_points"])
+    assert r1["p"].tobytes() == want["resulting_parameters"].tobytes()
+    assert r1["chi"].tobytes() == want["chi"].tobytes()
+    ea.close(), eb.close(), t.close(), cmds.close()
