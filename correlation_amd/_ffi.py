@@ -100,6 +100,7 @@ SYMBOLS = {
     "lk_tracker_set_annular_domain": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]),
     "lk_tracker_set_blob_domain": (C.c_int, [_P, _F, C.c_int, C.c_float, C.c_float]),
     "lk_tracker_sector_count": (C.c_int, [_P]),
+    "lk_tracker_enable_report": (C.c_int, [_P, C.c_int]),
     "lk_tracker_blob_contour": (C.c_int, [_P, C.POINTER(_F), _I]),
     "lk_tracker_begin_frame": (C.c_int, [_P, C.c_int, _P, _F]),
     "lk_tracker_end_frame": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_char_p, _P, _I, _I]),

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <charconv>
 #include <future>
 #include <sstream>
 #include <string>
@@ -35,9 +36,9 @@ struct lk_tracker {
   std::vector<float> contour;
   int results_i = 0, results_j = 0;
   std::vector<lk_frame_result> res, before; // frame_results[]; state before begin_frame
-  std::vector<lk_sector_command> last_cmds;
-  std::ostringstream report;
-  std::string report_cache, err;
+  std::string report; // the CSV text so far
+  bool report_enabled = true;
+  std::string err;
   bool begun = false;
 
   int fail(int code, const char *what) {
@@ -46,70 +47,84 @@ struct lk_tracker {
   }
 };
 
+// std::ostream << float / int / bool with default flags, which is what the reference's report
+// stream does: "%g" with 6 significant digits == std::to_chars(general, 6); an ostringstream
+// round trip per number would cost more than the solve on 50 000-sector grids.
+static void put(std::string &r, float v) {
+  char buf[48];
+  if (std::isnan(v)) { // num_put prints what printf does
+    r += std::signbit(v) ? "-nan" : "nan";
+    return;
+  }
+  auto res = std::to_chars(buf, buf + sizeof(buf), v, std::chars_format::general, 6);
+  r.append(buf, res.ptr);
+}
+static void put(std::string &r, int v) {
+  char buf[16];
+  auto res = std::to_chars(buf, buf + sizeof(buf), v);
+  r.append(buf, res.ptr);
+}
+
 static void initialize_report(lk_tracker *t) { // manager_class.cpp:2473-2525
-  std::ostringstream &r = t->report;
-  r.str("");
-  r << "Frame#"
-    << ","
-    << "und_file_string"
-    << ","
-    << "def_file_string"
-    << ","
-    << "und_global_center_x"
-    << ","
-    << "und_global_center_y"
-    << ","
-    << "und_center_x"
-    << ","
-    << "und_center_y"
-    << ","
-    << "def_global_center_x"
-    << ","
-    << "def_global_center_y"
-    << ","
-    << "def_center_x"
-    << ","
-    << "def_center_y"
-    << ",";
-  for (int p = 0; p < t->P; ++p)
-    r << "parameter_" << p << ",";
-  for (int p = 0; p < t->P; ++p)
-    r << "Initial_guess_" << p << ",";
-  r << "und_global_angle(rad)"
-    << ","
-    << "def_global_angle(rad)"
-    << ","
-    << "und_angle(rad)"
-    << ","
-    << "def_angle(rad)"
-    << ","
-    << "def_angle(deg)"
-    << ",";
-  r << "chi"
-    << ","
-    << "number_of_points"
-    << ","
-    << "iterations"
-    << ","
-    << "error_status"
-    << ","
-    << "error_code" << std::endl;
+  std::string &r = t->report;
+  r.clear();
+  for (const char *name : {"Frame#", "und_file_string", "def_file_string", "und_global_center_x",
+                           "und_global_center_y", "und_center_x", "und_center_y", "def_global_center_x",
+                           "def_global_center_y", "def_center_x", "def_center_y"}) {
+    r += name;
+    r += ',';
+  }
+  for (const char *stem : {"parameter_", "Initial_guess_"})
+    for (int p = 0; p < t->P; ++p) {
+      r += stem;
+      put(r, p);
+      r += ',';
+    }
+  for (const char *name : {"und_global_angle(rad)", "def_global_angle(rad)", "und_angle(rad)", "def_angle(rad)",
+                           "def_angle(deg)", "chi", "number_of_points", "iterations", "error_status"}) {
+    r += name;
+    r += ',';
+  }
+  r += "error_code\n";
 }
 
 static void add_frame_to_report(lk_tracker *t, int frame, const char *und, const char *def) { // :2430-2471
-  std::ostringstream &r = t->report;
+  if (!t->report_enabled)
+    return;
+  std::string &r = t->report;
   for (const lk_frame_result &s : t->res) {
-    r << frame << "," << und << "," << def << "," << s.und_global_center_x << "," << s.und_global_center_y << ","
-      << s.und_center_x << "," << s.und_center_y << "," << s.def_global_center_x << "," << s.def_global_center_y
-      << "," << s.def_center_x << "," << s.def_center_y << ",";
-    for (int p = 0; p < t->P; ++p)
-      r << s.resulting_parameters[p] << ",";
-    for (int p = 0; p < t->P; ++p)
-      r << s.initial_guess[p] << ",";
-    r << s.und_global_angle << "," << s.def_global_angle << "," << s.und_angle << "," << s.def_angle << ","
-      << s.def_angle * 180 / kPI << ",";
-    r << s.chi << "," << s.number_of_points << "," << s.iterations << "," << (s.error_status != 0) << ","
-      << s.error_code << std::endl;
+    put(r, frame);
+    r += ',';
+    r += und;
+    r += ',';
+    r += def;
+    r += ',';
+    for (float v : {s.und_global_center_x, s.und_global_center_y, s.und_center_x, s.und_center_y,
+                    s.def_global_center_x, s.def_global_center_y, s.def_center_x, s.def_center_y}) {
+      put(r, v);
+      r += ',';
+    }
+    for (int p = 0; p < t->P; ++p) {
+      put(r, s.resulting_parameters[p]);
+      r += ',';
+    }
+    for (int p = 0; p < t->P; ++p) {
+      put(r, s.initial_guess[p]);
+      r += ',';
+    }
+    for (float v : {s.und_global_angle, s.def_global_angle, s.und_angle, s.def_angle, s.def_angle * 180 / kPI,
+                    s.chi}) {
+      put(r, v);
+      r += ',';
+    }
+    put(r, s.number_of_points);
+    r += ',';
+    put(r, s.iterations);
+    r += ',';
+    put(r, s.error_status != 0 ? 1 : 0);
+    r += ',';
+    put(r, s.error_code);
+    r += '\n';
   }
 }
 
@@ -314,6 +329,13 @@ int lk_tracker_set_blob_domain(lk_tracker *t, const float *contour_xy, int n_ver
 
 int lk_tracker_sector_count(const lk_tracker *t) { return t ? (int)t->res.size() : 0; }
 
+int lk_tracker_enable_report(lk_tracker *t, int enabled) {
+  if (!t)
+    return LK_ERROR_BAD_DOMAIN;
+  t->report_enabled = enabled != 0;
+  return LK_ERROR_NONE;
+}
+
 int lk_tracker_blob_contour(const lk_tracker *t, const float **contour_xy, int *n_vertices) {
   if (!t || t->contour.empty())
     return LK_ERROR_BAD_DOMAIN;
@@ -495,7 +517,7 @@ int lk_tracker_get_results(const lk_tracker *t, lk_frame_result *out) {
 int lk_tracker_report(const lk_tracker *t, char *buf, size_t cap, size_t *needed) {
   if (!t)
     return LK_ERROR_BAD_DOMAIN;
-  const std::string s = t->report.str();
+  const std::string &s = t->report;
   if (needed)
     *needed = s.size() + 1;
   if (buf && cap > 0) {

@@ -89,6 +89,9 @@ class SequenceTracker:
         c = np.ascontiguousarray(contour, np.float32).reshape(-1, 2)
         self._chk(self.lib.lk_tracker_set_blob_domain(self._h, _ffi.fptr(c), c.shape[0], x_center, y_center))
 
+    def enable_report(self, enabled):
+        self._chk(self.lib.lk_tracker_enable_report(self._h, int(bool(enabled))))
+
     @property
     def n_sectors(self):
         return self.lib.lk_tracker_sector_count(self._h)

@@ -94,6 +94,9 @@ int lk_tracker_set_annular_domain(lk_tracker *t, float r_inside, float r_outside
 int lk_tracker_set_blob_domain(lk_tracker *t, const float *contour_xy, int n_vertices, float x_center,
                                float y_center);
 int lk_tracker_sector_count(const lk_tracker *t);
+/* the CSV rows cost ~35 number conversions per sector and frame: callers that only read
+ * lk_tracker_get_results can switch them off (on by default) */
+int lk_tracker_enable_report(lk_tracker *t, int enabled);
 int lk_tracker_blob_contour(const lk_tracker *t, const float **contour_xy, int *n_vertices);
 
 /* Top half of the sector loop of one frame: adjust_*_domain + adjust_initial_guess for every

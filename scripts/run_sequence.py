@@ -47,3 +47,24 @@ for f in range(1, F):
         e.makeDefPyramidFromNxt()
 wall = time.perf_counter() - t0
 print(json.dumps({"config": wl.name, "frames": F, "pairs_per_s_wall": (F - 1) / wall, "per_frame": rows}))
+
+# the same sequence through the tracker-driven frame loop (include/lk_tracker.h):
+# manager bookkeeping + guesses on the host, records back per frame, CSV report optional
+from correlation_amd import tracker as tk  # noqa: E402
+
+for with_report in (False, True):
+    e2 = ca.HipCorrelationEngine(fitting_model=wl.model, py_stop=wl.py_stop)
+    t = tk.SequenceTracker(wl.model, tk.DOMAIN_RECT, tk.DEF_EULERIAN, tk.REF_FIRST, tk.ERRMODE_CONTINUE, lib=e2.lib)
+    t.set_rect_domain(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, c, c, wl.hs, wl.vs)
+    t.enable_report(with_report)
+    host_frames = [np.ascontiguousarray(f) for f in frames]
+    t0 = time.perf_counter()
+    done = tk.run_sequence(e2, t, host_frames)
+    wall2 = time.perf_counter() - t0
+    res = t.results()
+    u_true = 0.8 * (F - 1) + 1e-4 * (F - 1) * (res["und_center_x"] - c)
+    print(json.dumps({"tracker_frame_loop": True, "report": with_report, "pairs": done,
+                      "pairs_per_s_wall": done / wall2, "ms_per_pair_wall": 1e3 * wall2 / done,
+                      "median_abs_u_err_last": float(np.nanmedian(np.abs(res["resulting_parameters"][:, 0] - u_true))),
+                      "report_bytes": len(t.report())}))
+    e2.close(), t.close()
