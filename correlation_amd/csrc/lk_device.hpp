@@ -47,6 +47,7 @@ struct LkSolveArgs {
   uint32_t *queue;       // next unclaimed slot of this launch (persistent mode), zeroed per launch
   int n_sectors;         // sectors in this launch
   int chunk;             // non-persistent: ceil(#workgroups / 8), XCD-contiguous chunk length
+  int align;             // 1: the sectors of a wavefront (16/32-lane groups) descend the pyramid together
   int solo;              // 1: an idle half-wavefront may join its partner's sector (32-lane groups)
   int safe;              // 1: reference-exact handling of starved / ill-conditioned levels
   int persistent;        // 1: groups pull sectors from `queue`; 0: one sector per group by position

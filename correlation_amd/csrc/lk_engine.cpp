@@ -1027,6 +1027,11 @@ static LkSolveArgs base_args(lk_engine *e, const float *d_guess, lk_result *d_re
   a.precision = e->cfg.precision;
   a.max_iters = e->cfg.max_iters;
   a.solo = e->batch_invariant ? 0 : 1;
+  static const int align = [] { // tuning hook; alignment never changes a record's bits
+    const char *f = std::getenv("LK_ALIGN");
+    return f ? std::atoi(f) : 1;
+  }();
+  a.align = align;
   return a;
 }
 

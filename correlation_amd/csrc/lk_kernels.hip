@@ -839,6 +839,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
   const float min_lambda = 1e-9f, max_lambda = 1e9f;
   bool first_fetch = true;
   int phase = PH_FETCH;
+  int cur_level = 0; // register copy of the cold state's level (alignment of the groups of a wavefront)
   LevelCtx c{};
   SumsT S;
   bool wide = false; // GROUP == 32 only: both halves of the wavefront work on one sector
@@ -877,6 +878,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
   auto enter_level = [&](Cold &k) { // top of the level loop (:373-408)
     const LkLevelView lv = a.lv[k.level];
     translate<P>(p, k.level_old, k.level);
+    cur_level = k.level;
     k.error = LK_ERROR_NONE;
     k.lambda = 0.0001f;
     k.lg_chi = FLT_MAX;
@@ -944,7 +946,14 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
   };
 
   for (;;) {
-    if (phase == PH_FETCH) { // take the next sector
+    bool may_fetch = true;
+    if constexpr (GROUP > 1 && GROUP < kWave) {
+      // aligned wavefronts fetch together: a group that finished early waits for its
+      // neighbours, so that the next batch of sectors starts the pyramid in step
+      if (a.align && a.persistent)
+        may_fetch = __ballot(phase < PH_FETCH) == 0ull;
+    }
+    if (phase == PH_FETCH && may_fetch) { // take the next sector
       int slot = 0;
       if (!a.persistent) { // one sector per group, handed out by position (see launch_solve_g)
         // workgroups are dealt round-robin over the 8 XCDs: give each XCD one contiguous run
@@ -1038,11 +1047,27 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
           };
           take_ptr(c.und), take_ptr(c.def), take_ptr(c.xy);
           take(phase);
+          take(cur_level);
           if (!active)
             cold_slot = cold_lds + (((int)threadIdx.x / GROUP) ^ 1) * kColdWords;
           active = true;
           wide = true;
         }
+      }
+    }
+    if constexpr (GROUP > 1 && GROUP < kWave) {
+      // Level alignment: the trip count of an evaluation is set by the group with the most
+      // samples, so a wavefront whose groups sit at different pyramid levels pays the finest
+      // level's price for every step.  A group that is ahead (at a finer level than the
+      // coarsest one still being solved in its wavefront) skips steps until the others have
+      // caught up; then all of them walk the expensive fine level together.
+      if (a.align) {
+        int wave_level = -1;
+        for (int L = a.py_stop; L >= a.py_start && wave_level < 0; L -= a.py_step)
+          if (__ballot(active && cur_level == L) != 0ull)
+            wave_level = L;
+        if (active && cur_level < wave_level)
+          active = false; // hold: no evaluation, no state change in this step
       }
     }
     LevelCtx ce = c;
