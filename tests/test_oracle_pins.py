@@ -81,3 +81,23 @@ def test_oracle_vs_live_reference_pieces(oracle):
             out = np.zeros((max(n, 1), 2), np.float32)
             R.ref_blob_points(F(c), nv, F(out), n)
             assert mine is not None and len(mine) == n and np.array_equal(mine, out[:n])
+
+
+def test_oracle_regression_vectors(oracle):
+    """tests/golden/oracle_regression.npz freezes the oracle's own outputs (pyramid, bicubic known
+    answers, evaluations, damped solves, Newton_Raphson traces incl. reject path and out-of-image,
+    sample lists, a sector grid, a 3-frame sequence report): any change of the restatement or of
+    its build flags shows up here bit for bit.  (Regression vectors - not reference-generated.)"""
+    import importlib.util
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_regression", os.path.join(here, "make_oracle_regression.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = np.load(os.path.join(here, "oracle_regression.npz"))
+    got = mod.compute(stored=want)
+    assert sorted(got) == sorted(want.files)
+    for k in want.files:
+        a, b = np.asarray(got[k]), want[k]
+        assert a.dtype == b.dtype and a.shape == b.shape, k
+        assert a.tobytes() == b.tobytes(), f"{k}: oracle output changed"
