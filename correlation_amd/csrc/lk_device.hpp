@@ -29,6 +29,8 @@ struct LkHandoff {
   uint32_t n_evals, n_sample_evals, n_point_iters;
 };
 
+constexpr int kLkMidWords = 32; // Cold (22) + p (6) + phase
+
 struct LkSolveArgs {
   const LkLevelView *lv; // [LK_MAX_LEVELS] in device memory
   const float2 *center;  // [S] level-0 centre of each sector
@@ -43,6 +45,14 @@ struct LkSolveArgs {
   int team_w;
   float *team_partials;  // [n_sectors][2][team_w][32]: per-workgroup sums, double-buffered by step parity
   uint32_t *team_arrivals; // [n_sectors]: monotonic arrival counter (zeroed per launch)
+  // Stragglers of the starved-level kernel: after `eval_cap` evaluations a lane parks its sector
+  // mid-level (kLkMidWords words of state) and appends it to `finish_list`; the 16-lane
+  // finisher (`finisher` = 1) resumes it with reference-order sums spread over 16 lanes.
+  int eval_cap;
+  int finisher;
+  uint32_t *mid_state;    // [S][kLkMidWords]
+  uint32_t *finish_list;  // [S]
+  uint32_t *finish_count; // [1], zeroed before the starved-level kernel
   LkHandoff *handoff;    // [S] written by the starved-level kernel, read by the others (may be null)
   uint32_t *queue;       // next unclaimed slot of this launch (persistent mode), zeroed per launch
   int n_sectors;         // sectors in this launch

@@ -155,6 +155,8 @@ struct lk_engine {
   std::vector<int> h_class; // size class of every sector
   DevBuf<uint32_t> d_single, d_queue;
   DevBuf<LkHandoff> d_handoff;
+  DevBuf<uint32_t> d_mid, d_finish_list, d_finish_count; // stragglers of the starved-level kernel
+  int eval_cap = 32; // evaluations a lane of the starved-level kernel spends on one sector (0: no cap)
   int team_w = 0; // workgroups per sector of the team class
   DevBuf<float> d_team_partials;
   DevBuf<uint32_t> d_team_arrivals;
@@ -247,6 +249,9 @@ void lk_destroy(lk_engine *e) {
   e->d_single.release();
   e->d_queue.release();
   e->d_handoff.release();
+  e->d_mid.release();
+  e->d_finish_list.release();
+  e->d_finish_count.release();
   e->d_scratch.release();
   e->d_warp.release();
   if (e->own_stream)
@@ -738,6 +743,16 @@ static int commit_impl(lk_engine *e, bool keep_state) {
   HIPCHK(e->d_single.ensure(1));
   HIPCHK(e->d_queue.ensure(8 * kNumClasses));
   HIPCHK(e->d_handoff.ensure((size_t)S));
+  bool any_starved = false;
+  for (int c = 0; c < kNumClasses; ++c)
+    any_starved = any_starved || e->class_starved[c];
+  if (any_starved) {
+    HIPCHK(e->d_mid.ensure((size_t)S * kLkMidWords));
+    HIPCHK(e->d_finish_list.ensure((size_t)S));
+    HIPCHK(e->d_finish_count.ensure(1));
+  }
+  if (const char *f = std::getenv("LK_EVAL_CAP")) // tuning / test hook
+    e->eval_cap = std::atoi(f);
   HIPCHK(e->d_scratch.ensure(64));
   e->S = S;
   e->committed = true;
@@ -1035,6 +1050,28 @@ static LkSolveArgs base_args(lk_engine *e, const float *d_guess, lk_result *d_re
   return a;
 }
 
+// Starved levels: the one-lane-per-sector kernel (bit-identical sums and QR), whose lanes park
+// a sector after eval_cap evaluations, then the 16-lane finisher for the parked ones.  Both
+// leave an LkHandoff record per sector for the lane-group kernel that follows.
+static int launch_starved(lk_engine *e, LkSolveArgs &a) {
+  a.handoff = e->d_handoff.p;
+  a.eval_cap = e->eval_cap > 0 ? e->eval_cap : 0;
+  a.mid_state = e->d_mid.p;
+  a.finish_list = e->d_finish_list.p;
+  a.finish_count = e->d_finish_count.p;
+  if (a.eval_cap > 0)
+    HIPCHK(hipMemsetAsync(e->d_finish_count.p, 0, sizeof(uint32_t), e->stream));
+  HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, 1, e->stream));
+  if (a.eval_cap > 0) {
+    LkSolveArgs f = a;
+    f.finisher = 1;
+    f.safe = 1;
+    HIPCHK(lk_launch_solve(f, e->cfg.fitting_model, e->cfg.interpolation, 16, e->stream));
+  }
+  a.eval_cap = 0;
+  return LK_ERROR_NONE;
+}
+
 static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
   if (e->timing)
     HIPCHK(hipEventRecord(e->ev_s0, e->stream));
@@ -1052,9 +1089,10 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
       a.team_partials = e->d_team_partials.p;
       a.team_arrivals = e->d_team_arrivals.p;
     }
-    if (e->class_starved[c]) { // coarsest level(s) first, one lane per sector
-      a.handoff = e->d_handoff.p;
-      HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, 1, e->stream));
+    if (e->class_starved[c]) { // coarsest level(s) first, one lane per sector (+ finisher)
+      int rc = launch_starved(e, a);
+      if (rc)
+        return rc;
     }
     HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, kGroupOfClass[c], e->stream));
   }
@@ -1131,8 +1169,9 @@ int lk_correlate(lk_engine *e, int sector, float *guess_inout, lk_result *out) {
   if (e->timing)
     HIPCHK(hipEventRecord(e->ev_s0, e->stream));
   if (e->class_starved[e->h_class[(size_t)sector]]) {
-    a.handoff = e->d_handoff.p;
-    HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, 1, e->stream));
+    int rc = launch_starved(e, a);
+    if (rc)
+      return rc;
   }
   HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, group, e->stream));
   if (e->timing) {

@@ -47,6 +47,11 @@ template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
   return v + __int_as_float(t);
 }
 
+// lane I of the own 16-lane row (row_newbcast, gfx90a and later)
+template <int I> __device__ __forceinline__ float dpp_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + I, 0xF, 0xF, false));
+}
+
 __device__ __forceinline__ uint32_t load_u32_unaligned(gptr<uint8_t> p) {
   uint32_t v;
   typedef uint32_t __attribute__((aligned(1))) u32_u;
@@ -280,7 +285,7 @@ struct TeamCtx {
 template <int MODEL, int INTERP, int GROUP, int THREADS>
 __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
                                          Sums<n_params(MODEL)> &S, float *lds, TeamCtx *team = nullptr,
-                                         bool wide = false) {
+                                         bool wide = false, bool ordered = false) {
   constexpr int P = n_params(MODEL);
   using SumsT = Sums<P>;
   const int team_w = (GROUP == 512 && team) ? team->w : 1;
@@ -294,6 +299,81 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
     S.v[i] = 0.f;
   bool bad = false;
   const int umaxr = c.urows - 1, umaxc = c.ucols - 1;
+  if constexpr (GROUP == 16) {
+    if (ordered) {
+      // Finisher of a starved level (at most 2P <= 12 samples): lane i of the row takes sample i
+      // in the REFERENCE's order, forms the rounded products there, and every lane then adds
+      // them up in sample order (row_newbcast reads lane j of the own row) - the same
+      // sequence of roundings as interpolation_class.cpp:722-749 and the one-lane kernel.
+      const int i = (int)threadIdx.x & 15;
+      const bool has = i < c.n;
+      float t[SumsT::N];
+#pragma unroll
+      for (int v = 0; v < SumsT::N; ++v)
+        t[v] = 0.f;
+      if (has) {
+        f32x2 q;
+        if (c.rw > 0) { // x outer, y inner (manager_class.cpp:1607-1611)
+          const int h = c.n / c.rw, col = i / h;
+          q.x = (float)(c.rx + col);
+          q.y = (float)(c.ry + (i - col * h));
+        } else {
+          q = c.xy[i];
+        }
+        float xd, yd, dx = 0.f, dy = 0.f;
+        Warp<MODEL>::apply(q.x, q.y, c.cx, c.cy, p, xd, yd, dx, dy);
+        int uix = (int)(q.x + 0.5f), uiy = (int)(q.y + 0.5f);
+        uix = min(max(uix, 0), umaxc);
+        uiy = min(max(uiy, 0), umaxr);
+        const float und_w = (float)c.und[(size_t)uiy * (size_t)c.ucols + (size_t)uix];
+        float W, Wx, Wy;
+        if (!sample_def<INTERP>(c.def, c.drows, c.dcols, xd, yd, W, Wx, Wy)) {
+          bad = true;
+        } else {
+          const float V = und_w - W;
+          float H[P];
+          Warp<MODEL>::jac(Wx, Wy, dx, dy, H);
+          int idx = 0;
+#pragma unroll
+          for (int p1 = 0; p1 < P; ++p1)
+#pragma unroll
+            for (int p2 = p1; p2 < P; ++p2)
+              t[idx++] = H[p1] * H[p2];
+#pragma unroll
+          for (int p1 = 0; p1 < P; ++p1)
+            t[SumsT::NA + p1] = H[p1] * V;
+          t[SumsT::N - 1] = V * V;
+        }
+      }
+      const unsigned long long badmask = __ballot(bad);
+#pragma unroll
+      for (int j = 0; j < 2 * P; ++j) {
+        const bool take = j < c.n;
+#pragma unroll
+        for (int v = 0; v < SumsT::N; ++v) {
+          float tj;
+          switch (j) { // row_newbcast:j (DPP control 0x150 + j)
+          case 0: tj = dpp_bcast<0>(t[v]); break;
+          case 1: tj = dpp_bcast<1>(t[v]); break;
+          case 2: tj = dpp_bcast<2>(t[v]); break;
+          case 3: tj = dpp_bcast<3>(t[v]); break;
+          case 4: tj = dpp_bcast<4>(t[v]); break;
+          case 5: tj = dpp_bcast<5>(t[v]); break;
+          case 6: tj = dpp_bcast<6>(t[v]); break;
+          case 7: tj = dpp_bcast<7>(t[v]); break;
+          case 8: tj = dpp_bcast<8>(t[v]); break;
+          case 9: tj = dpp_bcast<9>(t[v]); break;
+          case 10: tj = dpp_bcast<10>(t[v]); break;
+          default: tj = dpp_bcast<11>(t[v]); break;
+          }
+          const float sum = S.v[v] + tj;
+          S.v[v] = take ? sum : S.v[v];
+        }
+      }
+      const int row = ((int)threadIdx.x & 63) >> 4;
+      return ((badmask >> (16 * row)) & 0xffffull) != 0ull;
+    }
+  }
   // Lane groups walk implicit rectangles x-fastest so that neighbouring lanes read
   // neighbouring pixels of one image row (a 16-lane group touches 1-2 cache lines per load
   // instead of 16).  The reference enumerates y-fastest (manager_class.cpp:1607-1611); only
@@ -826,6 +906,9 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
   using SumsT = Sums<P>;
   constexpr bool COLD_IN_LDS = GROUP > 1 && GROUP <= kWave;
   constexpr bool STARVED = GROUP == 1; // one lane per sector: solves only the starved top levels
+  // the 16-lane SAFE instance doubles as the finisher of that kernel's stragglers (a.finisher)
+  const bool finisher = SAFE && GROUP == 16 && a.finisher != 0;
+  const bool starved = STARVED || finisher;
   constexpr int RED_WORDS = GROUP > kWave ? (THREADS / kWave) * (SumsT::N + 1) + 1 : 1;
   __shared__ float lds[RED_WORDS];
   __shared__ uint32_t cold_lds[COLD_IN_LDS ? (THREADS / GROUP) * kColdWords : 1];
@@ -875,13 +958,9 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
     phase = PH_FETCH;
   };
 
-  auto enter_level = [&](Cold &k) { // top of the level loop (:373-408)
+  auto level_context = [&](const Cold &k) { // what the lanes need to know about the sector at k.level
     const LkLevelView lv = a.lv[k.level];
-    translate<P>(p, k.level_old, k.level);
     cur_level = k.level;
-    k.error = LK_ERROR_NONE;
-    k.lambda = 0.0001f;
-    k.lg_chi = FLT_MAX;
     const uint32_t off = lv.off[k.s];
     const int4 rc = lv.rect[k.s];
     c.rx = rc.x;
@@ -899,11 +978,37 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
     const float inv = 1.f / (float)(1 << k.level); // pyramid_class.cpp:357-361
     c.cx = k.level == 0 ? k.c0x : k.c0x * inv;
     c.cy = k.level == 0 ? k.c0y : k.c0y * inv;
+  };
+
+  auto enter_level = [&](Cold &k) { // top of the level loop (:373-408)
+    translate<P>(p, k.level_old, k.level);
+    k.error = LK_ERROR_NONE;
+    k.lambda = 0.0001f;
+    k.lg_chi = FLT_MAX;
+    level_context(k);
 #pragma unroll
     for (int i = 0; i < P; ++i)
       k.lg_p[i] = p[i];
     phase = PH_EVAL0;
   };
+
+  // STARVED kernel, a.eval_cap > 0: a lane that has used up its evaluations parks the sector
+  // in the middle of its level for the 16-lane finisher (the 63 other lanes of the wavefront
+  // are not kept waiting for one sector that runs into max_iters)
+  auto park = [&](const Cold &k) {
+    uint32_t *m = a.mid_state + (size_t)k.s * kLkMidWords;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(&k);
+#pragma unroll
+    for (int i = 0; i < kColdWords; ++i)
+      m[i] = w[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      m[kColdWords + i] = __float_as_uint(p[i]);
+    m[kColdWords + 6] = (uint32_t)phase;
+    a.finish_list[atomicAdd(a.finish_count, 1u)] = (uint32_t)k.s;
+    phase = PH_FETCH;
+  };
+  int steps = 0; // evaluations of the current sector in this kernel (STARVED: eval_cap)
 
   auto finish_sector = [&](const Cold &k, const float (&evaluated)[6]) { // results of Newton_Raphson (:638-639, :848-870)
     if ((int)threadIdx.x % GROUP == 0 && team.rank == 0) {
@@ -936,7 +1041,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
         a.stats[(size_t)k.s * 4 + 2] = k.n_point_iters;
         a.stats[(size_t)k.s * 4 + 3] = 0;
       }
-      if (STARVED) {
+      if (starved) {
         LkHandoff h{};
         h.level = a.py_start - 1; // finished
         a.handoff[k.s] = h;
@@ -974,7 +1079,26 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
           slot = (int)atomicAdd(a.queue, 1u);
         slot = __shfl(slot, ((int)threadIdx.x & 63) & ~(GROUP - 1), 64);
       }
-      if (slot < a.n_sectors) {
+      steps = 0;
+      if (finisher) { // resume a sector the starved-level kernel parked in the middle of a level
+        if (slot < (int)*a.finish_count) {
+          Cold k;
+          const int s_idx = (int)a.finish_list[slot];
+          const uint32_t *m = a.mid_state + (size_t)s_idx * kLkMidWords;
+          uint32_t *w = reinterpret_cast<uint32_t *>(&k);
+#pragma unroll
+          for (int i = 0; i < kColdWords; ++i)
+            w[i] = m[i];
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+            p[i] = __uint_as_float(m[kColdWords + i]);
+          phase = (int)m[kColdWords + 6];
+          level_context(k);
+          cold.store(cold_slot, k);
+        } else {
+          phase = PH_EXIT;
+        }
+      } else if (slot < a.n_sectors) {
         Cold k{};
         k.s = a.order ? (int)a.order[slot] : slot;
         const float2 c0 = a.center[k.s];
@@ -1073,7 +1197,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
     LevelCtx ce = c;
     if (!active)
       ce.n = 0;
-    const bool err = evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds, &team, wide);
+    const bool err = evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds, &team, wide, finisher);
     if (active) {
       Cold k = cold.load(cold_slot);
       float evaluated[6]; // the parameters this evaluation ran at, in level-0 scale
@@ -1100,7 +1224,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
 #pragma unroll
         for (int i = 0; i < P; ++i)
           tent[i] = p[i];
-        damped_step<P, SAFE || STARVED>(S, lam_use, c.scaling, p, STARVED); // p += dp (compute_model_parameters)
+        damped_step<P, SAFE || STARVED>(S, lam_use, c.scaling, p, starved); // p += dp (compute_model_parameters)
         if (phase == PH_EVAL0) {
           ++k.n_point_iters;
           k.lg_chi = chi;
@@ -1154,7 +1278,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
         if (k.level < a.py_start) {
           translate<P>(p, k.level_old, 0);
           finished = true;
-        } else if (STARVED && level_count(k.level, k.s) > 2 * P) {
+        } else if (starved && level_count(k.level, k.s) > 2 * P) {
           handed = true;
         } else {
           enter_level(k);
@@ -1164,6 +1288,8 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
         finish_sector(k, evaluated);
       else if (handed)
         hand_over(k);
+      else if (STARVED && a.eval_cap > 0 && ++steps >= a.eval_cap)
+        park(k);
       else
         cold.store(cold_slot, k);
     }
@@ -1537,6 +1663,18 @@ static hipError_t launch_solve_gs(const LkSolveArgs &a, hipStream_t st) {
   b.persistent = force_persistent >= 0 ? force_persistent : (want > 2 * resident ? 1 : 0);
   if (GROUP == 1)
     b.persistent = 0; // every lane takes exactly one sector
+  if (GROUP == 16 && SAFE && a.finisher) {
+    // the finisher pulls parked sectors from finish_list until *finish_count (known only on
+    // the device) is used up: as many wavefronts as could be needed, capped by what is resident
+    b.persistent = 1;
+    b.chunk = 0;
+    hipError_t qe = hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st);
+    if (qe != hipSuccess)
+      return qe;
+    hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, GROUP, THREADS, SAFE>),
+                       dim3((unsigned)(want < resident ? want : resident)), dim3(THREADS), 0, st, b);
+    return hipGetLastError();
+  }
   if (GROUP == 512 && a.team_w > 1) {
     // teams wait on each other: every workgroup of the launch must be resident at once
     b.team_w = a.team_w < resident / a.n_sectors ? a.team_w : resident / a.n_sectors;

@@ -793,3 +793,42 @@ def test_update_sector_equals_the_frame_loop(mode):
     assert r1["p"].tobytes() == want["resulting_parameters"].tobytes()
     assert r1["chi"].tobytes() == want["chi"].tobytes()
     ea.close(), eb.close(), t.close(), cmds.close()
+
+
+@pytest.mark.gpu
+def test_finisher_of_parked_sectors_is_bit_identical(oracle, monkeypatch):
+    """The lanes of the one-lane-per-sector kernel park a sector after LK_EVAL_CAP evaluations
+    and a 16-lane finisher resumes it in the middle of its level with the products summed in
+    the reference's sample order (row_newbcast) and the same QR: every record must keep its
+    bits whatever the cap (0 = no finisher, 1 = everything goes through it), including explicit
+    lists, all models, and against the CPU oracle on the starved level alone."""
+    und, dfm = ca.speckle.speckle_pair(768, 768, p=(1.3, -0.7, 0.0005, 0.0, 0.0, -0.00025), seed=13)
+    xdim, ydim, cen = oracle.rect_sector_geometry(32.0, 32.0, 735.0, 735.0, 39, 39)
+    lists = [oracle.rect_points(cx - xdim, cy - ydim, cx + xdim, cy + ydim) for cx, cy in cen]
+
+    def run(cap, model, py_start, explicit):
+        monkeypatch.setenv("LK_EVAL_CAP", str(cap))
+        e = ca.HipCorrelationEngine(fitting_model=model, py_start=py_start, py_stop=3)
+        e.set_undeformed_image(und)
+        e.set_deformed_image(dfm)
+        if explicit:   # every third sample of each sector: explicit lists, centre = their mean
+            for s, pts in enumerate(lists[:400]):
+                e.set_sector_points(s, pts[::3].copy())
+        else:
+            e.set_rect_grid(32.0, 32.0, 735.0, 735.0, 39, 39)
+        e.commit_sectors()
+        got = e.correlate_all(np.zeros(6, np.float32))
+        e.close()
+        return got
+
+    o = oracle.Oracle(py_start=3, py_stop=3)
+    o.set_image(0, und)
+    o.set_image(1, dfm)
+    want3 = o.correlate_sectors(lists, centers=cen.astype(np.float32))
+    for cap in (1, 3, 16):
+        assert run(cap, ca.FM_UVUXUYVXVY, 3, False).tobytes() == want3.tobytes(), cap
+    for model, py_start, explicit in ((ca.FM_UVUXUYVXVY, 0, False), (ca.FM_UVQ, 0, False), (ca.FM_UV, 2, False),
+                                      (ca.FM_UVUXUYVXVY, 0, True)):
+        ref = run(0, model, py_start, explicit)
+        for cap in (1, 5):
+            assert run(cap, model, py_start, explicit).tobytes() == ref.tobytes(), (model, py_start, explicit, cap)
