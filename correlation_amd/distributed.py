@@ -71,3 +71,66 @@ class ShardedCorrelator:
             _, cnt = shard_range(self.total, r, self.world)
             parts.append(out[r, :cnt].reshape(-1).view(rec))
         return np.concatenate(parts)
+
+
+class ShardedSequence:
+    """A tracked sequence (include/lk_tracker.h) over several GPUs - BASELINE config 4's shape.
+
+    Every rank keeps the full tracker (host bookkeeping of ALL sectors is cheap and, fed with
+    the same all-gathered records, identical everywhere) and an engine that holds only its
+    block of sectors, including their guess history and moved sample lists - so a frame costs
+    one broadcast of the new image and one all-gather of 48-byte records, nothing else
+    (SURVEY.md section 8e).  `engine` needs the HipCorrelationEngine methods used below."""
+
+    def __init__(self, engine, tracker, dist=None, device=None):
+        self.sc = ShardedCorrelator(engine, dist, device)
+        self.e, self.t = engine, tracker
+        self.S = tracker.n_sectors
+        self.first, self.count = shard_range(self.S, self.sc.rank, self.sc.world)
+        self.sc.total, self.sc.first, self.sc.count = self.S, self.first, self.count
+
+    def _apply(self, frame, cmds):
+        from . import tracker as tk
+        mine = cmds[self.first:self.first + self.count]
+        if frame == 0:
+            self.e.clear_sectors()
+            for s, c in enumerate(mine):
+                kind = int(c["kind"])
+                if kind == tk.SECTOR_RECT:
+                    self.e.resetPolygon_rect(s, int(c["x0"]), int(c["y0"]), int(c["x1"]), int(c["y1"]))
+                elif kind == tk.SECTOR_ANNULAR:
+                    self.e.resetPolygon_annular(s, c["r"], c["dr"], c["a"], c["da"], c["cx"], c["cy"], int(c["as"]))
+                else:
+                    raise ValueError("a blob domain is one sector: nothing to shard")
+            self.e.commit_sectors()
+        elif len(mine) and int(mine[0]["kind"]) != tk.SECTOR_KEEP:
+            centers = np.stack([mine["center_x"], mine["center_y"]], 1) if int(mine[0]["use_center"]) else None
+            if int(mine[0]["kind"]) == tk.SECTOR_TRANSLATE:
+                self.e.translate_sectors(np.stack([mine["offset_x"], mine["offset_y"]], 1), centers)
+            else:
+                self.e.rewarp_sectors(centers)
+
+    def run(self, frames, names=None):
+        """frames: list of uint8 images (their content matters on rank 0 only).  Returns the
+        number of pairs correlated; the report is `tracker.report()` (same on every rank)."""
+        from . import tracker as tk
+        from ._ffi import IMG_DEF, IMG_UND
+        names = names or [f"frame{i}" for i in range(len(frames))]
+        previous = self.t.cfg.reference_image == tk.REF_PREVIOUS
+        self.sc.broadcast_frame(IMG_UND, frames[0])
+        und_name, done = names[0], 0
+        for k in range(len(frames) - 1):
+            if k > 0 and previous:      # image roles, manager_class.cpp:1386-1407
+                self.e.makeUndPyramidFromDef()
+                und_name = names[k]
+            self.sc.broadcast_frame(IMG_DEF, frames[k + 1])
+            cmds, guesses = self.t.begin_frame(k)
+            self._apply(k, cmds)
+            records = self.sc.correlate_all(guesses[self.first:self.first + self.count])
+            first_unsolved, stop = self.t.end_frame(k, und_name, names[k + 1], records)
+            if first_unsolved < self.first + self.count and k > 0:
+                self.e.restore_sectors(max(0, first_unsolved - self.first))
+            done = k + 1
+            if stop:
+                break
+        return done

@@ -82,3 +82,87 @@ def test_two_rank_gloo_run_equals_single_process(tmp_path, oracle):
     for rank in (0, 1):
         got = np.load(tmp_path / f"res{rank}.npy").view(oracle.RESULT_DTYPE).reshape(-1)
         assert got.tobytes() == want.tobytes(), f"rank {rank}: gathered records differ from the 1-process run"
+
+
+SEQ_WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, os.environ["LK_ROOT"])
+    import torch.distributed as dist
+    import correlation_amd as ca
+    from correlation_amd import speckle, tracker as tk
+    from correlation_amd.distributed import ShardedSequence
+    from oracle import lk_oracle as lo
+
+    class OracleEngine:  # CPU stand-in with the engine's interface (sequence subset)
+        def __init__(self):
+            self.o = lo.Oracle(model=lo.FM_UVUXUYVXVY)
+            self.lists, self.cen = [], []
+        def set_image(self, slot, px):
+            self.o.set_image(slot, px)
+        def makeUndPyramidFromDef(self):
+            self.o.und_from_def()
+        def clear_sectors(self):
+            self.lists, self.cen = [], []
+        def resetPolygon_rect(self, s, x0, y0, x1, y1):
+            assert s == len(self.lists)
+            self.lists.append(lo.rect_points(x0, y0, x1, y1))
+            self.cen.append(((x0 + x1) * 0.5, (y0 + y1) * 0.5))
+        def commit_sectors(self):
+            pass
+        def translate_sectors(self, offsets, centers=None):
+            for s, pts in enumerate(self.lists):
+                out = np.empty_like(pts)
+                out[:, 0] = np.trunc((np.float32(offsets[s][0]) + pts[:, 0]).astype(np.float32) + np.float32(0.5))
+                out[:, 1] = np.trunc((np.float32(offsets[s][1]) + pts[:, 1]).astype(np.float32) + np.float32(0.5))
+                self.lists[s] = out
+                self.cen[s] = tuple(centers[s])
+        def correlate_all(self, guesses=None):
+            return self.o.correlate_sectors(self.lists, centers=np.array(self.cen, np.float32), guesses=guesses)
+
+    dist.init_process_group("gloo")
+    rank = dist.get_rank()
+    frames = speckle.speckle_sequence(192, 192, 4, velocity=(0.9, -0.5), dilation=4e-4, seed=3)
+    if rank != 0:
+        frames = [np.zeros_like(f) for f in frames]      # only rank 0 has the images
+    mode = int(os.environ["LK_SEQ_MODE"])
+    t = tk.SequenceTracker(ca.FM_UVUXUYVXVY, tk.DOMAIN_RECT, mode, tk.REF_PREVIOUS if mode == 1 else tk.REF_FIRST,
+                           tk.ERRMODE_CONTINUE, [0.5, -0.25, 0, 0, 0, 0])
+    t.set_rect_domain(30.0, 30.0, 161.0, 161.0, 95.5, 95.5, 3, 3)
+    seq = ShardedSequence(OracleEngine(), t, dist)
+    assert seq.run(frames, [f"f{i}" for i in range(4)]) == 3
+    open(os.path.join(os.environ["LK_OUT"], f"report{rank}.csv"), "w").write(t.report())
+    dist.destroy_process_group()
+""")
+
+
+def test_two_rank_sharded_sequence_equals_the_manager_oracle(tmp_path, oracle, engine_lib):
+    """BASELINE config 4's shape on two gloo ranks: every rank keeps the full tracker and its own
+    block of sectors; per frame one broadcast of the image and one all-gather of the records.
+    Both ranks must end with the report the single-process manager oracle writes."""
+    import pytest
+    from correlation_amd import speckle
+    from oracle import lk_manager_oracle as mo
+    script = tmp_path / "seq_worker.py"
+    script.write_text(SEQ_WORKER)
+    frames = speckle.speckle_sequence(192, 192, 4, velocity=(0.9, -0.5), dilation=4e-4, seed=3)
+    for mode, ref, port in ((mo.DEF_EULERIAN, mo.REF_FIRST, "29541"), (mo.DEF_LAGRANGIAN, mo.REF_PREVIOUS, "29542")):
+        env = dict(os.environ, LK_ROOT=ROOT, LK_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", LK_SEQ_MODE=str(mode))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+               "--master-addr", "127.0.0.1", "--master-port", port, str(script)]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        o = oracle.Oracle(model=oracle.FM_UVUXUYVXVY)
+        o.set_image(0, frames[0])
+        o.set_image(1, frames[1])
+        m = mo.ManagerOracle(o, 3, mo.DOMAIN_RECT, mode, ref, mo.ERRMODE_CONTINUE, [0.5, -0.25, 0, 0, 0, 0])
+        m.set_rect_domain(30.0, 30.0, 161.0, 161.0, 95.5, 95.5, 3, 3)
+        for k in range(3):
+            if k > 0:
+                if ref == mo.REF_PREVIOUS:
+                    o.und_from_def()
+                o.set_image(2, frames[k + 1])
+                o.def_from_nxt()
+            m.run_frame(k, "f0" if ref == mo.REF_FIRST else f"f{k}", f"f{k + 1}")
+        for rank in (0, 1):
+            assert open(tmp_path / f"report{rank}.csv").read() == m.report_text(), (mode, rank)

@@ -832,3 +832,26 @@ def test_finisher_of_parked_sectors_is_bit_identical(oracle, monkeypatch):
         ref = run(0, model, py_start, explicit)
         for cap in (1, 5):
             assert run(cap, model, py_start, explicit).tobytes() == ref.tobytes(), (model, py_start, explicit, cap)
+
+
+@pytest.mark.gpu
+def test_sharded_sequence_on_the_engine():
+    """correlation_amd.distributed.ShardedSequence (the multi-GPU shape of config 4: tracker
+    everywhere, sectors sharded) on one rank drives the HIP engine through the same calls as
+    lk_sequence_run and must write the same report."""
+    from correlation_amd import tracker as tk
+    from correlation_amd.distributed import ShardedSequence
+    frames = ca.speckle.speckle_sequence(256, 256, 4, velocity=(0.9, -0.5), dilation=4e-4, seed=3)
+    names = [f"f{i}" for i in range(4)]
+    reports = []
+    for sharded in (False, True):
+        e = ca.HipCorrelationEngine()
+        t = tk.SequenceTracker(ca.FM_UVUXUYVXVY, tk.DOMAIN_RECT, tk.DEF_LAGRANGIAN, tk.REF_PREVIOUS, lib=e.lib)
+        t.set_rect_domain(40.0, 44.0, 215.0, 211.0, 127.5, 127.5, 4, 3)
+        if sharded:
+            assert ShardedSequence(e, t).run(frames, names) == 3
+        else:
+            assert tk.run_sequence(e, t, frames, names) == 3
+        reports.append(t.report())
+        e.close(), t.close()
+    assert reports[0] == reports[1]
