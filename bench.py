@@ -56,6 +56,80 @@ def cpu_baseline(wl, und, dfm, budget_sectors):
     return out, len(pick)
 
 
+def other_configs(ca):
+    """BASELINE configs 3, 4 (one pair of its sector geometry) and 5 on this GPU: solve time of
+    one launch sequence, counters, and the distance to the synthetic ground truth.  Extra
+    evidence next to the headline line - never part of `value`."""
+    from correlation_amd.workload import C4, C5
+    out = {}
+
+    def timed(e, n=3):
+        g = np.zeros(6, np.float32)
+        r = e.correlate_all(g)
+        ms = []
+        for _ in range(n):
+            e.correlate_all(g)
+            ms.append(e.stats()["solve_ms"])
+        st = e.stats()
+        ms = float(np.median(ms))
+        return r, {"solve_ms": ms, "sectors": int(len(r)), "point_iterations_per_s": st["point_iterations"] / (ms * 1e-3),
+                   "algorithmic_GBps": st["algorithmic_bytes"] / (ms * 1e-3) / 1e9,
+                   "evaluations_per_sector": st["evaluations"] / st["sectors"],
+                   "error_free_fraction": float((r["error_code"] == 0).mean())}
+
+    def rect(wl, truth, seed):
+        und, dfm = ca.speckle.speckle_pair(wl.size, wl.size, p=truth, seed=seed, device="cuda")
+        e = ca.HipCorrelationEngine(fitting_model=wl.model, py_stop=wl.py_stop)
+        e.set_undeformed_image(und)
+        e.set_deformed_image(dfm)
+        e.set_rect_grid(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, wl.hs, wl.vs)
+        e.commit_sectors()
+        r, m = timed(e)
+        c = wl.size / 2.0
+        ok = r["error_code"] == 0
+        u_true = truth[0] + truth[2] * (r["und_cx"] - c) + truth[3] * (r["und_cy"] - c)
+        m["median_abs_u_minus_truth"] = float(np.median(np.abs(r["p"][:, 0] - u_true)[ok]))
+        m["workload"] = wl.name
+        e.close()
+        return m
+
+    try:
+        out["C4_one_pair"] = rect(C4, C4.truth, 7)
+    except Exception as ex:  # extra evidence must never take the headline line down
+        out["C4_one_pair"] = {"error": repr(ex)}
+    try:
+        out["C5"] = rect(C5, (1.3, -0.7, 0.0005, 0.0, 0.0, -0.00025), 13)
+    except Exception as ex:
+        out["C5"] = {"error": repr(ex)}
+    try:
+        truth = (1.1, 0.6, 0.0008, 0.0004, -0.0004, 0.0012)
+        und, dfm = ca.speckle.speckle_pair(4096, 4096, p=truth, seed=11, device="cuda")
+        e = ca.HipCorrelationEngine(fitting_model=ca.FM_UVUXUYVXVY)
+        e.set_undeformed_image(und)
+        e.set_deformed_image(dfm)
+        rs, as_, ri, ro = 8, 32, 600.0, 1800.0
+        dr, da = np.float32((ro - ri) / rs), np.float32(2 * np.pi) / np.float32(as_)
+        s = 0
+        for i in range(rs):
+            for j in range(as_):
+                e.resetPolygon_annular(s, np.float32(ri + i * dr), dr, np.float32(j) * da, da, 2048.0, 2048.0, as_)
+                s += 1
+        t = 2 * np.pi * np.arange(64) / 64
+        rad = np.where(np.arange(64) % 2 == 0, 1500.0, 900.0)
+        e.resetPolygon_blob(s, np.stack([2048 + rad * np.cos(t), 2048 + rad * np.sin(t)], 1).astype(np.float32))
+        e.commit_sectors()
+        r, m = timed(e)
+        u_true = truth[0] + truth[2] * (r["und_cx"] - 2048) + truth[3] * (r["und_cy"] - 2048)
+        m["max_abs_u_minus_truth"] = float(np.abs(r["p"][:, 0] - u_true).max())
+        m["largest_sector_samples"] = int(r["n_points"].max())
+        m["workload"] = "C3: 4096x4096, 8x32 annular sectors + one 64-vertex blob, affine, pyramid 0/1/2"
+        out["C3"] = m
+        e.close()
+    except Exception as ex:
+        out["C3"] = {"error": repr(ex)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,6 +137,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sectors", type=int, default=10000)
+    ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -231,6 +306,9 @@ def main():
                 "max_rel_dchi": float((np.abs(res["chi"][xs] - res_1["chi"]) / np.abs(res_1["chi"])).max()),
                 "iterations_equal_fraction": float((res["iterations"][xs] == res_1["iterations"]).mean()),
             }
+        if world == 1 and not args.no_other_configs and not use_dist:
+            e.close()
+            line["other_configs"] = other_configs(ca)
         print(json.dumps(line))
     e.close()
     if use_dist:
