@@ -285,15 +285,19 @@ struct TeamCtx {
 template <int MODEL, int INTERP, int GROUP, int THREADS>
 __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
                                          Sums<n_params(MODEL)> &S, float *lds, TeamCtx *team = nullptr,
-                                         bool wide = false, bool ordered = false) {
+                                         bool wide = false, bool ordered = false, int width = 0) {
   constexpr int P = n_params(MODEL);
   using SumsT = Sums<P>;
   const int team_w = (GROUP == 512 && team) ? team->w : 1;
   const int team_rank = (GROUP == 512 && team) ? team->rank : 0;
   // GROUP == 32, `wide` (wavefront-uniform): the partner half-wavefront has run out of work
   // and both halves evaluate the same sector with all 64 lanes (see "solo" in the kernel)
-  const int lane0 = (GROUP == 32 && wide) ? ((int)threadIdx.x & 63) : team_rank * GROUP + (int)threadIdx.x % GROUP;
-  const int stride = (GROUP == 32 && wide) ? 64 : GROUP * team_w;
+  // GROUP == 16, `width` (wavefront-uniform, 16 / 32 / 64): the rows of the wavefront that ran
+  // out of work have joined the sectors still being solved (see "adaptive width" in the kernel)
+  const int lane0 = (GROUP == 32 && wide)    ? ((int)threadIdx.x & 63)
+                    : (GROUP == 16 && width) ? ((int)threadIdx.x & (width - 1))
+                                             : team_rank * GROUP + (int)threadIdx.x % GROUP;
+  const int stride = (GROUP == 32 && wide) ? 64 : (GROUP == 16 && width) ? width : GROUP * team_w;
 #pragma unroll
   for (int i = 0; i < SumsT::N; ++i)
     S.v[i] = 0.f;
@@ -449,6 +453,19 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
   for (int i = 0; i < SumsT::N; ++i)
     S.v[i] = row16_sum(S.v[i]);
   if constexpr (GROUP == 16) {
+    if (width >= 32) { // a + b == b + a: every lane of the widened group ends with the same bits
+#pragma unroll
+      for (int i = 0; i < SumsT::N; ++i)
+        S.v[i] += __shfl_xor(S.v[i], 16, 64);
+      if (width == 64) {
+#pragma unroll
+        for (int i = 0; i < SumsT::N; ++i)
+          S.v[i] += __shfl_xor(S.v[i], 32, 64);
+        return badmask != 0ull;
+      }
+      const int half = ((int)threadIdx.x & 63) >> 5;
+      return ((badmask >> (32 * half)) & 0xffffffffull) != 0ull;
+    }
     const int row = ((int)threadIdx.x & 63) >> 4;
     return ((badmask >> (16 * row)) & 0xffffull) != 0ull;
   } else if constexpr (GROUP == 32) { // two sectors per wavefront: add the partner row
@@ -926,6 +943,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
   LevelCtx c{};
   SumsT S;
   bool wide = false; // GROUP == 32 only: both halves of the wavefront work on one sector
+  int width = 16;    // GROUP == 16 only: lanes per sector right now (16 / 32 / 64), wavefront-uniform
   TeamCtx team;
   if constexpr (GROUP == 512) {
     if (a.team_w > 1) {
@@ -1058,6 +1076,13 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
       if (a.align && a.persistent)
         may_fetch = __ballot(phase < PH_FETCH) == 0ull;
     }
+    if constexpr (GROUP == 16) {
+      // a batch of an aligned persistent wavefront is over: back to one sector per row
+      if (width != 16 && a.align && a.persistent && may_fetch) {
+        width = 16;
+        cold_slot = cold_lds + ((int)threadIdx.x / GROUP) * kColdWords;
+      }
+    }
     if (phase == PH_FETCH && may_fetch) { // take the next sector
       int slot = 0;
       if (!a.persistent) { // one sector per group, handed out by position (see launch_solve_g)
@@ -1179,6 +1204,52 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
         }
       }
     }
+    if constexpr (GROUP == 16) {
+      // Adaptive width: rows whose sector is finished (out of work for good, or waiting for the
+      // common fetch of an aligned persistent wavefront) join the sectors still being solved -
+      // 4 x 16 lanes become 2 x 32 or 1 x 64.  The joining lanes copy the warm state of the
+      // sector's home row and share its cold slot; all lanes of a widened group then run the
+      // identical state machine on identical sums.  It shortens exactly the part of a launch
+      // that is otherwise spent waiting for the slowest sectors.
+      const unsigned long long act = __ballot(active);
+      const bool idle_ok = (a.align && a.persistent) || __ballot(phase == PH_EXIT) == ~act;
+      if (a.solo && width < 64 && idle_ok && !finisher) {
+        // home rows of the sectors in progress (a widened group shows up in all its rows)
+        const unsigned rows = ((act & 0xffffull) ? 1u : 0u) | ((act & 0xffff0000ull) ? 2u : 0u) |
+                              ((act & 0xffff00000000ull) ? 4u : 0u) | ((act & 0xffff000000000000ull) ? 8u : 0u);
+        const unsigned sect = width == 16 ? rows : ((rows & 3u) ? 1u : 0u) | ((rows & 12u) ? 4u : 0u);
+        const int n_sect = __builtin_popcount(sect);
+        const int new_width = n_sect == 1 ? 64 : (n_sect == 2 && width == 16) ? 32 : width;
+        if (new_width != width) {
+          const int first = __builtin_ctz(sect), last = 31 - __builtin_clz(sect);
+          const int lane = (int)threadIdx.x & 63;
+          const int src_row = (new_width == 64 || lane < 32) ? first : last;
+          const int src_lane = src_row * 16 + (lane & 15);
+          auto take = [&](auto &v) { v = __shfl(v, src_lane, 64); };
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+            take(p[i]);
+          take(c.rx), take(c.ry), take(c.rw), take(c.n);
+          take(c.urows), take(c.ucols), take(c.drows), take(c.dcols);
+          take(c.scaling), take(c.cx), take(c.cy);
+          auto take_ptr = [&](auto &ptr) {
+            unsigned long long bits = (unsigned long long)(uintptr_t)ptr;
+            uint32_t lo32 = (uint32_t)bits, hi32 = (uint32_t)(bits >> 32);
+            take(lo32), take(hi32);
+            ptr = (decltype(+ptr))(uintptr_t)(((unsigned long long)hi32 << 32) | lo32);
+          };
+          take_ptr(c.und), take_ptr(c.def), take_ptr(c.xy);
+          take(phase);
+          take(cur_level);
+          // the sector keeps the cold slot it was fetched into
+          int slot_idx = (int)(cold_slot - cold_lds);
+          take(slot_idx);
+          cold_slot = cold_lds + slot_idx;
+          active = phase < PH_FETCH;
+          width = new_width;
+        }
+      }
+    }
     if constexpr (GROUP > 1 && GROUP < kWave) {
       // Level alignment: the trip count of an evaluation is set by the group with the most
       // samples, so a wavefront whose groups sit at different pyramid levels pays the finest
@@ -1197,7 +1268,8 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
     LevelCtx ce = c;
     if (!active)
       ce.n = 0;
-    const bool err = evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds, &team, wide, finisher);
+    const bool err = evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds, &team, wide, finisher,
+                                                             GROUP == 16 ? width : 0);
     if (active) {
       Cold k = cold.load(cold_slot);
       float evaluated[6]; // the parameters this evaluation ran at, in level-0 scale
