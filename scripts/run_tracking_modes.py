@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Wall time per pair of the tracker-driven frame loop (lk_sequence_run) on BASELINE config 4's
+geometry for the three deformation descriptions (Eulerian / Lagrangian / strict Lagrangian)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import correlation_amd as ca  # noqa: E402
+from correlation_amd import tracker as tk  # noqa: E402
+from correlation_amd.workload import C4 as wl  # noqa: E402
+
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+xs, ys, amps = ca.speckle.blobs(wl.size, wl.size, seed=7)
+frames = []
+for f in range(F):
+    p = (0.8 * f, -0.4 * f, 1e-4 * f, 0.0, 0.0, 1e-4 * f)
+    xd, yd = ca.speckle.deform(xs, ys, wl.size, wl.size, p)
+    frames.append(np.ascontiguousarray(ca.speckle._render_torch(wl.size, wl.size, xd, yd, amps, 2.5, "cuda")))
+c = wl.size / 2.0
+for name, mode, ref in (("eulerian/first", tk.DEF_EULERIAN, tk.REF_FIRST), ("lagrangian/previous", tk.DEF_LAGRANGIAN, tk.REF_PREVIOUS),
+                        ("strict_lagrangian/previous", tk.DEF_STRICT_LAGRANGIAN, tk.REF_PREVIOUS)):
+    e = ca.HipCorrelationEngine(fitting_model=wl.model, py_stop=wl.py_stop)
+    t = tk.SequenceTracker(wl.model, tk.DOMAIN_RECT, mode, ref, tk.ERRMODE_CONTINUE, lib=e.lib)
+    t.set_rect_domain(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, c, c, wl.hs, wl.vs)
+    t.enable_report(False)
+    t0 = time.perf_counter()
+    done = tk.run_sequence(e, t, frames)
+    wall = time.perf_counter() - t0
+    r = t.results()
+    print(json.dumps({"mode": name, "pairs": done, "ms_per_pair_wall": 1e3 * wall / done,
+                      "error_free_fraction": float((r["error_code"] == 0).mean()),
+                      "median_u_last": float(np.median(r["resulting_parameters"][:, 0]))}), flush=True)
+    e.close(), t.close()
