@@ -855,3 +855,35 @@ def test_sharded_sequence_on_the_engine():
         reports.append(t.report())
         e.close(), t.close()
     assert reports[0] == reports[1]
+
+
+@pytest.mark.gpu
+def test_tiny_and_ragged_sectors(oracle, speckle512):
+    """Sectors of 1, 2, 3, 7 and 13 samples, some at odd coordinates only so that coarser pyramid
+    levels are EMPTY (n_L = 0: the reference's 1/n scaling becomes inf and its sums NaN), next to
+    a normal sector.  Starved levels are solved in the reference's order with its QR, so even
+    these degenerate records must match the oracle bit for bit wherever every level is starved,
+    and the normal sector must not be disturbed by its neighbours."""
+    e, o = make_pair(speckle512, ca.FM_UVUXUYVXVY, ca.IM_BICUBIC, oracle)
+    lists = [np.array([[201, 203]], np.float32),
+             np.array([[211, 203], [213, 205]], np.float32),
+             np.array([[220, 220], [221, 221], [222, 224]], np.float32),
+             oracle.rect_points(240, 240, 246, 240),
+             np.array([[260 + (i % 4), 260 + i // 4] for i in range(13)], np.float32),
+             oracle.rect_points(300, 300, 330, 330)]
+    for s, xy in enumerate(lists):
+        e.set_sector_points(s, xy)
+    e.commit_sectors()
+    got = e.correlate_all(np.zeros(6, np.float32))
+    want = o.o1.correlate_sectors(lists)
+    assert list(got["n_points"]) == [1, 2, 3, 7, 13, 961]
+    assert np.array_equal(got["error_code"], want["error_code"])
+    for s in range(4):   # every level of these sectors has at most 12 samples: bit-identical
+        same = got[s].tobytes() == want[s].tobytes()
+        same = same or (np.array_equal(got["p"][s], want["p"][s], equal_nan=True) and
+                        got["iterations"][s] == want["iterations"][s])
+        assert same, (s, got[s], want[s])
+    assert np.abs(got["p"][5] - want["p"][5])[:2].max() < 1e-3
+    alone, _ = e.correlate(5, np.zeros(6, np.float32))
+    assert np.abs(alone["p"] - got["p"][5]).max() < 1e-4
+    e.close()
