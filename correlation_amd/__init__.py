@@ -7,7 +7,7 @@ and fails loudly if the library is missing.
 """
 from ._ffi import (ERROR_BAD_DOMAIN, ERROR_CORRELATION_MAX_ITERS_REACHED, ERROR_DEVICE,  # noqa: F401
                    ERROR_INTERPOLATION_OUT_OF_IMAGE, ERROR_NONE, FM_U, FM_UV, FM_UVQ,
-                   FM_UVUXUYVXVY, IM_BICUBIC, IM_BILINEAR, IM_NEAREST, IMG_DEF, IMG_NXT, IMG_UND,
+                   FM_UVUXUYVXVY, IM_BICUBIC, IM_BICUBIC_SEPARABLE, IM_BILINEAR, IM_NEAREST, IMG_DEF, IMG_NXT, IMG_UND,
                    LIB_PATH, N_PARAMS, RESULT_DTYPE, SYMBOLS, load_library)
 from .engine import HipCorrelationEngine, LkError  # noqa: F401
 from . import speckle  # noqa: F401

@@ -15,6 +15,7 @@ LK_MAX_LEVELS = 8
 
 # enums (include/lk_engine.h)
 IM_NEAREST, IM_BILINEAR, IM_BICUBIC = 0, 1, 2
+IM_BICUBIC_SEPARABLE = 3   # extension: same surface, separable evaluation (include/lk_engine.h)
 FM_U, FM_UV, FM_UVQ, FM_UVUXUYVXVY = 0, 1, 2, 3
 IMG_UND, IMG_DEF, IMG_NXT = 0, 1, 2
 (ERROR_NONE, ERROR_MODEL_OUT_OF_IMAGE, ERROR_INTERPOLATION_OUT_OF_IMAGE,

@@ -195,7 +195,7 @@ int lk_create(const lk_config *cfg, lk_engine **out) {
   if (!cfg || !out)
     return LK_ERROR_BAD_DOMAIN;
   *out = nullptr;
-  if (n_params_of(cfg->fitting_model) < 0 || cfg->interpolation < 0 || cfg->interpolation > 2)
+  if (n_params_of(cfg->fitting_model) < 0 || cfg->interpolation < 0 || cfg->interpolation > LK_IM_BICUBIC_SEPARABLE)
     return LK_ERROR_BAD_DOMAIN;
   if (cfg->py_step < 1 || cfg->py_start < 0 || cfg->py_stop < cfg->py_start ||
       cfg->py_stop >= LK_MAX_LEVELS || (cfg->py_stop - cfg->py_start) % cfg->py_step != 0)

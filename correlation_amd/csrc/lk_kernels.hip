@@ -83,6 +83,20 @@ __device__ __forceinline__ void cubic_1d(float p0, float p1, float p2, float p3,
   c3 = __builtin_fmaf(-0.5f, p0, __builtin_fmaf(1.5f, p1, __builtin_fmaf(-1.5f, p2, 0.5f * p3)));
 }
 
+// the 4x4 window as four (unaligned) dwords, rows iy-1..iy+2, columns ix-1..ix+2
+struct Window4 {
+  uint32_t r0, r1, r2, r3;
+};
+__device__ __forceinline__ Window4 load_window(gptr<uint8_t> def, int cols, int ix, int iy) {
+  gptr<uint8_t> base = def + (size_t)(iy - 1) * (size_t)cols + (size_t)(ix - 1);
+  Window4 w;
+  w.r0 = load_u32_unaligned(base);
+  w.r1 = load_u32_unaligned(base + cols);
+  w.r2 = load_u32_unaligned(base + 2 * (size_t)cols);
+  w.r3 = load_u32_unaligned(base + 3 * (size_t)cols);
+  return w;
+}
+
 // Value and gradient of the bicubic at (ix + dx - 1, iy + dy - 1), dx,dy in [1,2).
 // The four coefficients of monomial row jk are produced (exactly, see above) right before
 // they are consumed, so only the 16 x-transformed values stay live, and then W, dW/dx,
@@ -127,6 +141,19 @@ __device__ __forceinline__ void bicubic_sample(gptr<uint8_t> def, int cols, int 
   }
 }
 
+// Catmull-Rom weights of the four samples at -1, 0, 1, 2 for position t in [0, 1) and their
+// derivatives (Horner form)
+__device__ __forceinline__ void catmull_rom(float t, float (&w)[4], float (&g)[4]) {
+  w[0] = t * __builtin_fmaf(t, __builtin_fmaf(t, -0.5f, 1.0f), -0.5f);
+  w[1] = __builtin_fmaf(t * t, __builtin_fmaf(t, 1.5f, -2.5f), 1.0f);
+  w[2] = t * __builtin_fmaf(t, __builtin_fmaf(t, -1.5f, 2.0f), 0.5f);
+  w[3] = t * t * __builtin_fmaf(t, 0.5f, -0.5f);
+  g[0] = __builtin_fmaf(t, __builtin_fmaf(t, -1.5f, 2.0f), -0.5f);
+  g[1] = t * __builtin_fmaf(t, 4.5f, -5.0f);
+  g[2] = __builtin_fmaf(t, __builtin_fmaf(t, -4.5f, 4.0f), 0.5f);
+  g[3] = t * __builtin_fmaf(t, 1.5f, -1.0f);
+}
+
 // returns false when the sample leaves the image (error_interpolation_out_of_image)
 template <int INTERP>
 __device__ __forceinline__ bool sample_def(gptr<uint8_t> def, int rows, int cols, float xd,
@@ -137,6 +164,30 @@ __device__ __forceinline__ bool sample_def(gptr<uint8_t> def, int rows, int cols
     int ix = (int)xd, iy = (int)yd;
     float dx = xd - (float)ix + 1.f, dy = yd - (float)iy + 1.f;
     bicubic_sample(def, cols, ix, iy, dx, dy, W, Wx, Wy);
+    return true;
+  } else if constexpr (INTERP == LK_IM_BICUBIC_SEPARABLE) {
+    // The reference's bicubic patch (values + central differences on the cell's corners) is
+    // the Catmull-Rom spline; evaluated here as two 1-D kernels instead of 16 coefficients and
+    // monomials.  Same validity rule, same window; results equal to rounding, not bit for bit.
+    if (!(xd > 1.f && yd > 1.f && xd < (float)cols - 2.f && yd < (float)rows - 2.f))
+      return false;
+    const int ix = (int)xd, iy = (int)yd;
+    const float tx = xd - (float)ix, ty = yd - (float)iy;
+    const Window4 w = load_window(def, cols, ix, iy);
+    float wx[4], gx[4], wy[4], gy[4];
+    catmull_rom(tx, wx, gx);
+    catmull_rom(ty, wy, gy);
+    const uint32_t r[4] = {w.r0, w.r1, w.r2, w.r3};
+    float row_v[4], row_g[4]; // per image row: value and x-derivative along x
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float p0 = ub0(r[j]), p1 = ub1(r[j]), p2 = ub2(r[j]), p3 = ub3(r[j]);
+      row_v[j] = __builtin_fmaf(wx[3], p3, __builtin_fmaf(wx[2], p2, __builtin_fmaf(wx[1], p1, wx[0] * p0)));
+      row_g[j] = __builtin_fmaf(gx[3], p3, __builtin_fmaf(gx[2], p2, __builtin_fmaf(gx[1], p1, gx[0] * p0)));
+    }
+    W = __builtin_fmaf(wy[3], row_v[3], __builtin_fmaf(wy[2], row_v[2], __builtin_fmaf(wy[1], row_v[1], wy[0] * row_v[0])));
+    Wx = __builtin_fmaf(wy[3], row_g[3], __builtin_fmaf(wy[2], row_g[2], __builtin_fmaf(wy[1], row_g[1], wy[0] * row_g[0])));
+    Wy = __builtin_fmaf(gy[3], row_v[3], __builtin_fmaf(gy[2], row_v[2], __builtin_fmaf(gy[1], row_v[1], gy[0] * row_v[0])));
     return true;
   } else if constexpr (INTERP == LK_IM_BILINEAR) { // :140-195, :338-374
     if (!(xd > 0.f && yd > 0.f && xd < (float)(cols - 1) && yd < (float)(rows - 1)))
@@ -1800,6 +1851,7 @@ static hipError_t launch_solve_m(const LkSolveArgs &a, int interp, int group, hi
   switch (interp) {
   case LK_IM_NEAREST: return launch_solve_mi<MODEL, LK_IM_NEAREST>(a, group, st);
   case LK_IM_BILINEAR: return launch_solve_mi<MODEL, LK_IM_BILINEAR>(a, group, st);
+  case LK_IM_BICUBIC_SEPARABLE: return launch_solve_mi<MODEL, LK_IM_BICUBIC_SEPARABLE>(a, group, st);
   default: return launch_solve_mi<MODEL, LK_IM_BICUBIC>(a, group, st);
   }
 }
@@ -1820,6 +1872,7 @@ static hipError_t launch_eval_mg(const LkEvalArgs &a, int interp, hipStream_t st
   switch (interp) {
   case LK_IM_NEAREST: hipLaunchKernelGGL((lk_eval_kernel<MODEL, LK_IM_NEAREST, GROUP>), dim3(1), dim3(256), 0, st, a); break;
   case LK_IM_BILINEAR: hipLaunchKernelGGL((lk_eval_kernel<MODEL, LK_IM_BILINEAR, GROUP>), dim3(1), dim3(256), 0, st, a); break;
+  case LK_IM_BICUBIC_SEPARABLE: hipLaunchKernelGGL((lk_eval_kernel<MODEL, LK_IM_BICUBIC_SEPARABLE, GROUP>), dim3(1), dim3(256), 0, st, a); break;
   default: hipLaunchKernelGGL((lk_eval_kernel<MODEL, LK_IM_BICUBIC, GROUP>), dim3(1), dim3(256), 0, st, a); break;
   }
   return hipGetLastError();
@@ -1863,6 +1916,7 @@ hipError_t lk_launch_sample(int interp, const uint8_t *def, int rows, int cols, 
   switch (interp) {
   case LK_IM_NEAREST: hipLaunchKernelGGL((lk_sample_kernel<LK_IM_NEAREST>), grid, block, 0, st, def, rows, cols, pts, n, out); break;
   case LK_IM_BILINEAR: hipLaunchKernelGGL((lk_sample_kernel<LK_IM_BILINEAR>), grid, block, 0, st, def, rows, cols, pts, n, out); break;
+  case LK_IM_BICUBIC_SEPARABLE: hipLaunchKernelGGL((lk_sample_kernel<LK_IM_BICUBIC_SEPARABLE>), grid, block, 0, st, def, rows, cols, pts, n, out); break;
   default: hipLaunchKernelGGL((lk_sample_kernel<LK_IM_BICUBIC>), grid, block, 0, st, def, rows, cols, pts, n, out); break;
   }
   return hipGetLastError();

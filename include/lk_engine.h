@@ -44,7 +44,19 @@ typedef enum {
 } lk_error;
 
 /* interpolationModelEnum, enums.hpp:10-15 */
-typedef enum { LK_IM_NEAREST = 0, LK_IM_BILINEAR = 1, LK_IM_BICUBIC = 2 } lk_interpolation;
+typedef enum {
+  LK_IM_NEAREST = 0,
+  LK_IM_BILINEAR = 1,
+  LK_IM_BICUBIC = 2,
+  /* Extension (not a value of the reference's interpolationModelEnum): the same bicubic
+   * surface - the reference's 16-coefficient patch is the Catmull-Rom spline in exact
+   * arithmetic - evaluated in separable form, 4 + 4 weights and their derivatives.  It is
+   * closer to the exact spline than the reference's monomial evaluation (whose cancellation
+   * costs ~1e-3 grey levels), so it agrees with LK_IM_BICUBIC to that rounding, not bit for bit,
+   * and whole solves agree to ~1e-5 relative chi rather than inside the reference's own noise.
+   * About 40 % fewer instructions per sample.  Never selected implicitly. */
+  LK_IM_BICUBIC_SEPARABLE = 3
+} lk_interpolation;
 /* fittingModelEnum, enums.hpp:17-23: p = (u), (u,v), (u,v,q), (u,v,ux,uy,vx,vy) */
 typedef enum { LK_FM_U = 0, LK_FM_UV = 1, LK_FM_UVQ = 2, LK_FM_UVUXUYVXVY = 3 } lk_fitting_model;
 /* ImageType, enums.hpp:94-99 */

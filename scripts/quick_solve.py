@@ -19,7 +19,8 @@ if os.path.exists(cache):
 else:
     und, dfm = ca.speckle.speckle_pair(wl.size, wl.size, p=wl.truth, seed=7)
     np.savez(cache, und=und, dfm=dfm)
-e = ca.HipCorrelationEngine(fitting_model=wl.model, py_stop=wl.py_stop)
+e = ca.HipCorrelationEngine(fitting_model=wl.model, py_stop=wl.py_stop,
+                            interpolation=int(os.environ.get("LK_INTERP", ca.IM_BICUBIC)))
 e.set_undeformed_image(und)
 e.set_deformed_image(dfm)
 e.set_rect_grid(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, wl.hs, wl.vs)
