@@ -670,7 +670,7 @@ static int commit_impl(lk_engine *e, bool keep_state) {
     tot[c] += (size_t)n0;
   }
   for (int c = 0; c + 1 < kTeamClass; ++c) { // (nothing is promoted into the team class)
-    if (!cnt[c])
+    if (!cnt[c] || e->batch_invariant) // batch-invariant records: the group depends on the sector alone
       continue;
     // Wavefronts are dealt to SIMD slots as earlier ones retire; that only balances the
     // uneven per-sector iteration counts when there are a few times more wavefronts than

@@ -114,8 +114,9 @@ int lk_set_timing(lk_engine *e, int enabled);
  * the last bits between batches of different composition (a half-wavefront that runs out of
  * work joins its neighbour's sector, which changes the summation grouping - the same kind of
  * difference the reference shows between thread counts, correlation_class.cpp:169-186,253-275).
- * enabled = 1 switches that off: a sector then gets the same bits in any batch, shard or
- * single-sector call (about 20 % slower on small grids). */
+ * enabled = 1 switches that off (and fixes the lane group by the sector's own size instead of
+ * the batch's): a sector then gets the same bits in any batch, shard or single-sector call
+ * (about 20 % slower on small grids).  Call it before lk_commit_sectors. */
 int lk_set_batch_invariant(lk_engine *e, int enabled);
 /* block until everything queued by this engine has finished */
 int lk_synchronize(lk_engine *e);

@@ -946,3 +946,24 @@ def test_separable_bicubic_extension(oracle, speckle512):
     assert np.abs(got["p"] - want["p"])[:, 2:].max() < 1e-4
     assert (np.abs(got["chi"] - want["chi"]) / want["chi"]).max() < 5e-3
     e.close()
+
+
+@pytest.mark.gpu
+def test_batch_invariant_records_across_batch_sizes(speckle512):
+    """lk_set_batch_invariant(1): no solo / adaptive width and the lane group chosen from the
+    sector's own size - so a sector keeps its bits in the full grid, in shards of any size and
+    alignment, and alone (the default mode picks wider groups for small batches)."""
+    def run(first=0, count=-1):
+        e, _ = make_pair(speckle512, ca.FM_UVUXUYVXVY)
+        e.set_batch_invariant(True)
+        e.set_rect_grid(24.0, 24.0, 487.0, 487.0, 23, 23, first, count)
+        e.commit_sectors()
+        got = e.correlate_all(np.zeros(6, np.float32))
+        one, _ = e.correlate(min(5, len(got) - 1), np.zeros(6, np.float32))
+        assert one.tobytes() == got[min(5, len(got) - 1)].tobytes()
+        e.close()
+        return got
+
+    full = run()
+    for first, count in ((0, 7), (101, 64), (300, 229)):
+        assert run(first, count).tobytes() == full[first:first + count].tobytes(), (first, count)
