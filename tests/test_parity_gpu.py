@@ -809,7 +809,8 @@ def test_finisher_of_parked_sectors_is_bit_identical(oracle, monkeypatch):
     def run(cap, model, py_start, explicit):
         monkeypatch.setenv("LK_EVAL_CAP", str(cap))
         e = ca.HipCorrelationEngine(fitting_model=model, py_start=py_start, py_stop=3)
-        e.set_undeformed_image(und)
+        e.set_batch_invariant(True)   # the finer levels run in two passes (parked / not parked):
+        e.set_undeformed_image(und)    # only batch-invariant records are comparable bit for bit
         e.set_deformed_image(dfm)
         if explicit:   # every third sample of each sector: explicit lists, centre = their mean
             for s, pts in enumerate(lists[:400]):
