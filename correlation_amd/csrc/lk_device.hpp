@@ -43,6 +43,7 @@ struct LkSolveArgs {
   const uint32_t *order; // optional [n_sectors] indirection (size classes), may be null
   // teams: a giant sector is shared by team_w workgroups of the 512-thread kernel (0/1: off)
   int team_w;
+  int team_min_samples;  // a sector's team has ceil(n0 / team_min_samples) workgroups (<= team_w)
   float *team_partials;  // [n_sectors][2][team_w][32]: per-workgroup sums, double-buffered by step parity
   uint32_t *team_arrivals; // [n_sectors]: monotonic arrival counter (zeroed per launch)
   // Stragglers of the starved-level kernel: after `eval_cap` evaluations a lane parks its sector

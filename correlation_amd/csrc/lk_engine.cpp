@@ -112,6 +112,8 @@ static const int kTeamClass = 5;
 static const int kGroupOfClass[kNumClasses] = {16, 32, 64, 256, 512, 512};
 static const int kTeamSamples = 32768; // level-0 samples per workgroup of a team (64 per lane)
 static const int kMaxTeam = 128;
+static const int kTeamMinSamples = 4096; // a team workgroup is worth its all-to-all from 8 samples per lane on
+static const int kFewBigSectors = 128;   // at most this many 8-wavefront sectors: give them teams
 static int size_class(int n0) {
   return n0 <= 512 ? 0 : (n0 <= 2048 ? 1 : (n0 <= 8192 ? 2 : (n0 <= 65536 ? 3 : (n0 <= 8 * kTeamSamples ? 4 : 5))));
 }
@@ -158,6 +160,7 @@ struct lk_engine {
   DevBuf<uint32_t> d_mid, d_finish_list, d_finish_count; // stragglers of the starved-level kernel
   int eval_cap = 32; // evaluations a lane of the starved-level kernel spends on one sector (0: no cap)
   int team_w = 0; // workgroups per sector of the team class
+  int team_min_samples = 0; // per-sector team sizing (0: every team has team_w workgroups)
   DevBuf<float> d_team_partials;
   DevBuf<uint32_t> d_team_arrivals;
   DevBuf<float> d_scratch; // 64 floats for the stand-alone entry points
@@ -701,6 +704,17 @@ static int commit_impl(lk_engine *e, bool keep_state) {
   }
   e->team_w = 0;
   {
+    // A handful of big sectors (one ROI in the GUI, BASELINE config 1) cannot fill the chip with
+    // one workgroup each: when at most half of the CUs would be busy, every 8-wavefront sector
+    // gets a team as well.  The kernel sizes each sector's team by its own sample count
+    // (kTeamMinSamples per workgroup), the launch clamps the width to what is resident.
+    int n_big = 0;
+    for (int s = 0; s < S; ++s)
+      n_big += e->h_class[(size_t)s] >= kTeamClass - 1;
+    if (n_big > 0 && n_big <= kFewBigSectors && !e->batch_invariant)
+      for (int s = 0; s < S; ++s)
+        if (e->h_class[(size_t)s] == kTeamClass - 1)
+          e->h_class[(size_t)s] = kTeamClass;
     int n_team = 0, n0_max = 0;
     for (int s = 0; s < S; ++s)
       if (e->h_class[(size_t)s] == kTeamClass) {
@@ -708,8 +722,9 @@ static int commit_impl(lk_engine *e, bool keep_state) {
         n0_max = std::max(n0_max, e->hs[(size_t)s].n0());
       }
     if (n_team) {
-      int w = force_team > 1 ? force_team : (n0_max + kTeamSamples - 1) / kTeamSamples;
+      int w = force_team > 1 ? force_team : (n0_max + kTeamMinSamples - 1) / kTeamMinSamples;
       e->team_w = std::min(std::max(w, 2), kMaxTeam); // the launch clamps it to what is resident
+      e->team_min_samples = force_team > 1 ? 0 : kTeamMinSamples;
       HIPCHK(e->d_team_partials.ensure((size_t)n_team * 2 * (size_t)e->team_w * 32));
       HIPCHK(e->d_team_arrivals.ensure((size_t)n_team));
     }
@@ -1086,6 +1101,7 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
     a.safe = e->force_safe ? 1 : 0;
     if (c == kTeamClass) {
       a.team_w = e->team_w;
+      a.team_min_samples = e->team_min_samples;
       a.team_partials = e->d_team_partials.p;
       a.team_arrivals = e->d_team_arrivals.p;
     }
@@ -1163,6 +1179,7 @@ int lk_correlate(lk_engine *e, int sector, float *guess_inout, lk_result *out) {
   a.safe = e->force_safe ? 1 : 0;
   if (e->h_class[(size_t)sector] == kTeamClass) {
     a.team_w = e->team_w;
+    a.team_min_samples = e->team_min_samples;
     a.team_partials = e->d_team_partials.p;
     a.team_arrivals = e->d_team_arrivals.p;
   }

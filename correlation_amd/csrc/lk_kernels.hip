@@ -326,7 +326,7 @@ __device__ __forceinline__ float rows_sum(float v) { // after row16_sum: add the
 // parity; a workgroup cannot be two steps ahead of its team.  All workgroups of a launch
 // are resident (the host caps the grid), so the wait always ends; the spin is bounded anyway.
 struct TeamCtx {
-  int w = 1, rank = 0, slot = 0;
+  int w = 1, rank = 0, slot = 0, stride = 1; // stride: workgroups per slot in the partial-sum buffer
   uint32_t step = 0;
   float *partials = nullptr;
   uint32_t *arrivals = nullptr;
@@ -562,7 +562,7 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
       if constexpr (GROUP == 512) {
         if (team_w > 1) { // all-to-all of the workgroup totals inside the team
           ++team->step;
-          float *mine = team->partials + (((size_t)team->slot * 2 + (team->step & 1u)) * (size_t)team_w) * 32;
+          float *mine = team->partials + (((size_t)team->slot * 2 + (team->step & 1u)) * (size_t)team->stride) * 32;
           __syncthreads(); // everybody has its totals out of lds
           if (threadIdx.x == 0) {
 #pragma unroll
@@ -1003,6 +1003,20 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
       team.slot = (int)blockIdx.x / a.team_w;
       team.partials = a.team_partials;
       team.arrivals = a.team_arrivals;
+      team.stride = a.team_w;
+      // the team of a sector is as wide as its sample count is worth; the other workgroups
+      // of its slot leave at once (uniform over the workgroup, before any barrier)
+      if (a.team_min_samples > 0 && team.slot < a.n_sectors) {
+        const int sector = a.order ? (int)a.order[team.slot] : team.slot;
+        const LkLevelView lv0 = a.lv[0];
+        const int4 rc = lv0.rect[sector];
+        const int n0 = rc.z > 0 ? rc.w : (int)(lv0.off[sector + 1] - lv0.off[sector]);
+        int w = (n0 + a.team_min_samples - 1) / a.team_min_samples;
+        w = w < 1 ? 1 : (w > a.team_w ? a.team_w : w);
+        if (team.rank >= w)
+          return;
+        team.w = w;
+      }
     }
   }
 
@@ -1141,7 +1155,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
         // of sectors (neighbouring sectors share image rows in its L2)
         const int wg_slot = ((int)blockIdx.x & 7) * a.chunk + ((int)blockIdx.x >> 3);
         slot = first_fetch ? wg_slot * (THREADS / GROUP) + (int)threadIdx.x / GROUP : a.n_sectors;
-        if (GROUP == 512 && team.w > 1) // a team's workgroups all take the team's sector
+        if (GROUP == 512 && a.team_w > 1) // a team's workgroups all take the team's sector
           slot = first_fetch ? team.slot : a.n_sectors;
         first_fetch = false;
       } else if constexpr (GROUP > kWave) {
