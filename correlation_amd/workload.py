@@ -21,9 +21,14 @@ class RectWorkload:
 # pyramid 0/1/2 (the configuration the headline metric is quoted on)
 C2 = RectWorkload("C2: 2048x2048 speckle pair, 100x100 sectors of 19x19 samples, affine 6-DOF, bicubic, pyramid 0/1/2",
                   2048, 24.0, 2023.0, 100, 100, 2)
-# config 4's sector geometry (one pair of the sequence): 224x224 sectors of 9x9
-C4 = RectWorkload("C4: 2048x2048, 224x224 sectors of 9x9 samples, affine, pyramid 0/1/2",
+# config 4's sector geometry (one pair of the sequence).  SURVEY.md section 8d fixes hs = vs = 224 and
+# calls the sectors "9x9 = 81 samples"; the reference's grid rule (manager_class.cpp:283:
+# xdim = (1999 / 224 - 1) / 2 = 3) makes them 7x7 = 49 (levels 1 and 2 keep 9-16 and 1-4 samples:
+# two starved levels).  C4 follows the survey's grid; C4B is the nearest grid with 9x9 sectors.
+C4 = RectWorkload("C4: 2048x2048, 224x224 sectors of 7x7 samples, affine, pyramid 0/1/2",
                   2048, 24.0, 2023.0, 224, 224, 2)
+C4B = RectWorkload("C4B: 2048x2048, 222x222 sectors of 9x9 samples, affine, pyramid 0/1/2",
+                   2048, 24.0, 2023.0, 222, 222, 2)
 # config 5: 8192^2, 447x447 sectors of 17x17, 4 levels
 C5 = RectWorkload("C5: 8192x8192, 447x447 sectors of 17x17 samples, affine, pyramid 0/1/2/3",
                   8192, 32.0, 8159.0, 447, 447, 3)

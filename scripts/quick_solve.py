@@ -8,9 +8,9 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import correlation_amd as ca  # noqa: E402
-from correlation_amd.workload import C2, C4  # noqa: E402
+from correlation_amd.workload import C2, C4, C4B  # noqa: E402
 
-wl = {"C2": C2, "C4": C4}[sys.argv[1] if len(sys.argv) > 1 else "C2"]
+wl = {"C2": C2, "C4": C4, "C4B": C4B}[sys.argv[1] if len(sys.argv) > 1 else "C2"]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 cache = f"/tmp/speckle_{wl.size}.npz"
 if os.path.exists(cache):

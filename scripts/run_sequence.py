@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE config 4 on one GPU: a 2048^2 sequence (constant velocity 0.8,-0.4 px/frame + 1e-4
-dilation per frame), 224x224 sectors of 9x9, Eulerian / first-image reference, so the
+dilation per frame), 224x224 sectors of 7x7, Eulerian / first-image reference, so the
 constant-velocity initial guess is active from frame 2 on.  The next frame is uploaded on the
 engine's own stream while the current pair is solved.  Prints per-frame solve times."""
 import json

@@ -968,3 +968,70 @@ def test_batch_invariant_records_across_batch_sizes(speckle512):
     full = run()
     for first, count in ((0, 7), (101, 64), (300, 229)):
         assert run(first, count).tobytes() == full[first:first + count].tobytes(), (first, count)
+
+
+def _smooth_texture(n, seed):
+    """A random texture with a few pixels of correlation length, cheap at 8192^2 (box blurs by
+    cumulative sums; the speckle renderer would take minutes on the CPU at that size)."""
+    rng = np.random.default_rng(seed)
+    a = rng.random((n, n), dtype=np.float32)
+    for _ in range(3):
+        for axis in (0, 1):
+            c = np.cumsum(a, axis=axis, dtype=np.float64)
+            k = 5
+            c = np.take(c, np.arange(k, n), axis=axis) - np.take(c, np.arange(0, n - k), axis=axis)
+            pad = [(0, 0), (0, 0)]
+            pad[axis] = (k // 2, k - k // 2)
+            a = np.pad(c.astype(np.float32) / k, pad, mode="edge")
+    a -= a.min()
+    return (a * (255.0 / a.max())).astype(np.uint8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,hs,n0,stop,sectors", [(2048, 224, 49, 2, 50176), (8192, 447, 289, 3, 199809)])
+def test_configs_4_and_5_full_size_properties(size, hs, n0, stop, sectors):
+    """BASELINE configs 4 (one pair of its 50 176-sector grid) and 5 (199 809 sectors, 4 levels,
+    8192^2) at full size, through properties that need no oracle: the deformed frame is the
+    undeformed one moved by whole pixels, so every sector's translation is known exactly; the
+    batch is deterministic; in batch-invariant mode a shard of the grid reproduces the full run
+    bit for bit; the counters add up."""
+    und = _smooth_texture(size, 5)
+    dfm = np.roll(und, shift=(-2, 3), axis=(0, 1))          # content moves by u = +3, v = -2
+    lo_, hi_ = (24.0, size - 25.0) if size == 2048 else (32.0, size - 33.0)
+
+    def engine(invariant, first=0, count=-1):
+        e = ca.HipCorrelationEngine(fitting_model=ca.FM_UVUXUYVXVY, py_stop=stop)
+        e.set_batch_invariant(invariant)
+        e.set_undeformed_image(und)
+        e.set_deformed_image(dfm)
+        e.set_rect_grid(lo_, lo_, hi_, hi_, hs, hs, first, count)
+        e.commit_sectors()
+        return e
+
+    e = engine(False)
+    assert e.n_sectors == sectors and e.sector_info(0)[0] == n0
+    r1 = e.correlate_all(np.zeros(6, np.float32))
+    r2 = e.correlate_all(np.zeros(6, np.float32))
+    assert r1.tobytes() == r2.tobytes(), "the batch solve must be deterministic"
+    st = e.stats()
+    assert st["sectors"] == sectors and st["point_iterations"] >= (stop + 1) * sectors
+    assert st["algorithmic_bytes"] == 25 * st["sample_evaluations"] + 196 * st["evaluations"]
+    ok = r1["error_code"] == 0
+    assert ok.mean() > 0.97
+    # 7x7 samples cannot pin six parameters on every patch of texture (config 4's sectors are
+    # that small by the reference's own grid rule): the bulk must sit on the known shift
+    du, dv = np.abs(r1["p"][ok][:, 0] - 3.0), np.abs(r1["p"][ok][:, 1] + 2.0)
+    assert np.median(du) < 5e-3 and np.median(dv) < 5e-3
+    assert ((du < 0.2) & (dv < 0.2)).mean() > (0.5 if n0 < 100 else 0.7)   # (a starved level 3 scatters some)
+    assert np.median(np.abs(r1["p"][ok][:, 2:])) < 1e-3
+    assert (r1["n_points"] == n0).all()
+    e.close()
+    full = engine(True)
+    rf = full.correlate_all(np.zeros(6, np.float32))
+    full.close()
+    assert np.median(np.abs(rf["p"][ok] - r1["p"][ok])[:, :2]) < 1e-4    # same solutions, other summation grouping
+    first, count = sectors // 3 + 1, 4097
+    part = engine(True, first, count)
+    rp = part.correlate_all(np.zeros(6, np.float32))
+    part.close()
+    assert rp.tobytes() == rf[first:first + count].tobytes()
