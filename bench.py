@@ -60,7 +60,7 @@ def other_configs(ca):
     """BASELINE configs 3, 4 (one pair of its sector geometry) and 5 on this GPU: solve time of
     one launch sequence, counters, and the distance to the synthetic ground truth.  Extra
     evidence next to the headline line - never part of `value`."""
-    from correlation_amd.workload import C4, C5
+    from correlation_amd.workload import C4, C4B, C5
     out = {}
 
     def timed(e, n=3):
@@ -119,6 +119,10 @@ def other_configs(ca):
         out["C4_one_pair"] = rect(C4, C4.truth, 7)
     except Exception as ex:  # extra evidence must never take the headline line down
         out["C4_one_pair"] = {"error": repr(ex)}
+    try:
+        out["C4B_one_pair"] = rect(C4B, C4B.truth, 7)
+    except Exception as ex:
+        out["C4B_one_pair"] = {"error": repr(ex)}
     try:
         out["C5"] = rect(C5, (1.3, -0.7, 0.0005, 0.0, 0.0, -0.00025), 13)
     except Exception as ex:
