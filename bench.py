@@ -159,8 +159,8 @@ def other_configs(ca):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sectors", type=int, default=10000)
     ap.add_argument("--no-other-configs", action="store_true")
@@ -226,8 +226,8 @@ def main():
             pending["bcast"] = prefetch(k + 1)           # frame k+1 travels during this solve
             if pending["gather"][k % 2] is not None:
                 pending["gather"][k % 2].wait()          # records of frame k-2 have left d_ress[k % 2]
-        e.set_image_device(ca.IMG_UND, d_und.data_ptr(), wl.size, wl.size)            # pyramid build (und)
-        e.set_image_device(ca.IMG_DEF, d_defs[k % 2].data_ptr(), wl.size, wl.size)    # pyramid build (def)
+        # upload + pyramid build of both frames of the pair (one launch, CudaClass::resetImagePyramids)
+        e.set_image_pair_device(d_und.data_ptr(), d_defs[k % 2].data_ptr(), wl.size, wl.size)
         e.correlate_all_device(d_guess.data_ptr(), d_ress[k % 2].data_ptr())          # the solve
         if use_dist:                                     # gather of warp parameters
             pending["gather"][k % 2] = dist.all_gather_into_tensor(d_alls[k % 2], d_ress[k % 2], async_op=True)

@@ -61,6 +61,7 @@ SYMBOLS = {
     "lk_synchronize": (C.c_int, [_P]),
     "lk_set_image": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "lk_set_image_device": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
+    "lk_set_image_pair_device": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "lk_rotate_und_from_def": (C.c_int, [_P]),
     "lk_rotate_def_from_nxt": (C.c_int, [_P]),
     "lk_get_pyramid_level": (C.c_int, [_P, C.c_int, C.c_int, _P, _I, _I]),

@@ -28,8 +28,8 @@ hipError_t lk_launch_sample(int interp, const uint8_t *def, int rows, int cols, 
                             float4 *out, hipStream_t st);
 hipError_t lk_launch_pyramid(const uint8_t *src, int srows, int scols, uint8_t *dst, hipStream_t st);
 hipError_t lk_launch_set_views(const LkLevelView *h_views, LkLevelView *d_views, hipStream_t st);
-hipError_t lk_launch_pyramid2(const uint8_t *src, int step, int rows, int cols, uint8_t *l0, uint8_t *l1,
-                              uint8_t *l2, hipStream_t st);
+hipError_t lk_launch_pyramid2(int n_images, const uint8_t *const *src, const int *step, int rows, int cols,
+                              uint8_t *const *l0, uint8_t *const *l1, uint8_t *const *l2, hipStream_t st);
 hipError_t lk_launch_guess(const float2 *center, const float *last_p, float *prev_p, float *guess,
                            const float *global_guess, float gcx, float gcy, int n_sectors, int model,
                            int frame, int constant_velocity, hipStream_t st);
@@ -304,6 +304,34 @@ int lk_synchronize(lk_engine *e) {
 // ------------------------------------------------------------------------------------
 // images
 // ------------------------------------------------------------------------------------
+// level buffers of one slot for a rows x cols frame (+ two zeroed guard rows per level; the
+// pyramid kernels write every target pixel themselves, so the guard rows are only redone when
+// the geometry of the level changes)
+static int prepare_slot(lk_engine *e, DevImage &im, int rows, int cols, hipStream_t st) {
+  int r = rows, c = cols;
+  for (int l = 0; l <= e->cfg.py_stop; ++l) {
+    size_t need = (size_t)(r + 2) * (size_t)c + 16;
+    if (need > im.cap[l]) {
+      if (im.lvl[l]) {
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipFree(im.lvl[l]));
+        im.lvl[l] = nullptr;
+      }
+      HIPCHK(hipMalloc((void **)&im.lvl[l], need));
+      im.cap[l] = need;
+      im.guard_rows[l] = -1;
+    }
+    if (im.guard_rows[l] != r || im.guard_cols[l] != c) {
+      HIPCHK(hipMemsetAsync(im.lvl[l] + (size_t)r * (size_t)c, 0, 2 * (size_t)c + 16, st));
+      im.guard_rows[l] = r;
+      im.guard_cols[l] = c;
+    }
+    r /= 2;
+    c /= 2;
+  }
+  return LK_ERROR_NONE;
+}
+
 static int set_image_common(lk_engine *e, int slot, const void *src, bool src_on_device, int rows,
                             int cols, int step) {
   if (!e)
@@ -320,29 +348,12 @@ static int set_image_common(lk_engine *e, int slot, const void *src, bool src_on
     st = e->nxt_stream;
   }
   DevImage &im = e->img[slot];
-  int r = rows, c = cols;
-  for (int l = 0; l <= e->cfg.py_stop; ++l) {
-    size_t need = (size_t)(r + 2) * (size_t)c + 16;
-    if (need > im.cap[l]) {
-      if (im.lvl[l]) {
-        HIPCHK(hipStreamSynchronize(st));
-        HIPCHK(hipFree(im.lvl[l]));
-        im.lvl[l] = nullptr;
-      }
-      HIPCHK(hipMalloc((void **)&im.lvl[l], need));
-      im.cap[l] = need;
-      im.guard_rows[l] = -1;
-    }
-    // two zeroed guard rows below the image; the pyramid kernel writes every target pixel
-    // itself, so this is only redone when the geometry of the level changes
-    if (im.guard_rows[l] != r || im.guard_cols[l] != c) {
-      HIPCHK(hipMemsetAsync(im.lvl[l] + (size_t)r * (size_t)c, 0, 2 * (size_t)c + 16, st));
-      im.guard_rows[l] = r;
-      im.guard_cols[l] = c;
-    }
-    r /= 2;
-    c /= 2;
+  {
+    int rc = prepare_slot(e, im, rows, cols, st);
+    if (rc)
+      return rc;
   }
+  int r = rows, c = cols;
   const bool timed = slot != LK_IMG_NXT && e->timing;
   // two or more pyramid levels on a device-resident frame: upload copy + levels 1, 2 in ONE
   // launch (lk_pyramid2_kernel); host frames are copied first and the kernel runs in place
@@ -357,8 +368,9 @@ static int set_image_common(lk_engine *e, int slot, const void *src, bool src_on
   int l = 1;
   if (fused) {
     const bool in_place = !src_on_device;
-    HIPCHK(lk_launch_pyramid2(in_place ? im.lvl[0] : (const uint8_t *)src, in_place ? cols : step, rows, cols,
-                              im.lvl[0], im.lvl[1], im.lvl[2], st));
+    const uint8_t *srcs[1] = {in_place ? im.lvl[0] : (const uint8_t *)src};
+    const int steps[1] = {in_place ? cols : step};
+    HIPCHK(lk_launch_pyramid2(1, srcs, steps, rows, cols, &im.lvl[0], &im.lvl[1], &im.lvl[2], st));
     r = rows / 4;
     c = cols / 4;
     l = 3;
@@ -397,6 +409,51 @@ int lk_set_image_device(lk_engine *e, int slot, const void *device_pixels, int r
 }
 
 static void swap_images(DevImage &a, DevImage &b) { std::swap(a, b); }
+
+// CudaClass::resetImagePyramids takes the frames of a pair together (cuda_class.cu:475-519);
+// for device-resident frames both uploads and both pairs of pyramid levels share ONE launch.
+int lk_set_image_pair_device(lk_engine *e, const void *und_pixels, int und_step, const void *def_pixels,
+                             int def_step, int rows, int cols) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!und_pixels || !def_pixels || rows < 1 || cols < 1 || und_step < cols || def_step < cols)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_image_pair_device: bad arguments");
+  if (e->cfg.py_stop < 2 || rows < 4 || cols < 4) { // nothing to fuse
+    int rc = set_image_common(e, LK_IMG_UND, und_pixels, true, rows, cols, und_step);
+    return rc ? rc : set_image_common(e, LK_IMG_DEF, def_pixels, true, rows, cols, def_step);
+  }
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t st = e->stream;
+  DevImage &u = e->img[LK_IMG_UND], &d = e->img[LK_IMG_DEF];
+  int rc = prepare_slot(e, u, rows, cols, st);
+  if (!rc)
+    rc = prepare_slot(e, d, rows, cols, st);
+  if (rc)
+    return rc;
+  if (e->timing)
+    HIPCHK(hipEventRecord(e->ev_p0, st));
+  const uint8_t *srcs[2] = {(const uint8_t *)und_pixels, (const uint8_t *)def_pixels};
+  const int steps[2] = {und_step, def_step};
+  uint8_t *l0[2] = {u.lvl[0], d.lvl[0]}, *l1[2] = {u.lvl[1], d.lvl[1]}, *l2[2] = {u.lvl[2], d.lvl[2]};
+  HIPCHK(lk_launch_pyramid2(2, srcs, steps, rows, cols, l0, l1, l2, st));
+  for (DevImage *im : {&u, &d}) {
+    int r = rows / 4, c = cols / 4;
+    for (int l = 3; l <= e->cfg.py_stop; ++l) {
+      HIPCHK(lk_launch_pyramid(im->lvl[l - 1], r, c, im->lvl[l], st));
+      r /= 2;
+      c /= 2;
+    }
+    im->rows = rows;
+    im->cols = cols;
+    im->valid = true;
+  }
+  if (e->timing) {
+    HIPCHK(hipEventRecord(e->ev_p1, st));
+    e->pyr_timed = true;
+  }
+  e->lv_dirty = true;
+  return LK_ERROR_NONE;
+}
 
 int lk_rotate_und_from_def(lk_engine *e) { // pyramid_class.cpp:211-226: def is emptied
   if (!e)

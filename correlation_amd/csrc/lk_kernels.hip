@@ -1616,9 +1616,16 @@ __device__ __forceinline__ uint8_t pyr_tap(const uint8_t *win, int pitch) {
   return (uint8_t)acc;
 }
 
-__global__ void __launch_bounds__(256) lk_pyramid2_kernel(const uint8_t *__restrict__ src, int step, int rows,
-                                                          int cols, uint8_t *__restrict__ l0,
-                                                          uint8_t *__restrict__ l1, uint8_t *__restrict__ l2) {
+struct LkPyrJobs { // up to two images of the same size per launch (blockIdx.z picks one)
+  const uint8_t *src[2];
+  int step[2];
+  uint8_t *l0[2], *l1[2], *l2[2];
+};
+
+__global__ void __launch_bounds__(256) lk_pyramid2_kernel(LkPyrJobs jobs, int rows, int cols) {
+  const uint8_t *src = jobs.src[blockIdx.z];
+  const int step = jobs.step[blockIdx.z];
+  uint8_t *l0 = jobs.l0[blockIdx.z], *l1 = jobs.l1[blockIdx.z], *l2 = jobs.l2[blockIdx.z];
   __shared__ __attribute__((aligned(16))) uint8_t s0[kPyrR0 * kPyrPitch0];
   __shared__ __attribute__((aligned(16))) uint8_t s1[kPyrR1 * kPyrPitch1];
   const int rows1 = rows / 2, cols1 = cols / 2, rows2 = rows1 / 2, cols2 = cols1 / 2;
@@ -1955,12 +1962,20 @@ hipError_t lk_launch_set_views(const LkLevelView *h_views, LkLevelView *d_views,
 }
 
 // copy (src -> l0, skipped when src == l0) + levels 1 and 2 in one launch
-hipError_t lk_launch_pyramid2(const uint8_t *src, int step, int rows, int cols, uint8_t *l0, uint8_t *l1,
-                              uint8_t *l2, hipStream_t st) {
-  if (rows / 4 <= 0 || cols / 4 <= 0)
+hipError_t lk_launch_pyramid2(int n_images, const uint8_t *const *src, const int *step, int rows, int cols,
+                              uint8_t *const *l0, uint8_t *const *l1, uint8_t *const *l2, hipStream_t st) {
+  if (rows / 4 <= 0 || cols / 4 <= 0 || n_images < 1 || n_images > 2)
     return hipErrorInvalidValue;
-  dim3 grid((unsigned)((cols + kPyrT0 - 1) / kPyrT0), (unsigned)((rows + kPyrT0 - 1) / kPyrT0));
-  hipLaunchKernelGGL(lk_pyramid2_kernel, grid, dim3(256), 0, st, src, step, rows, cols, l0, l1, l2);
+  LkPyrJobs jobs{};
+  for (int i = 0; i < n_images; ++i) {
+    jobs.src[i] = src[i];
+    jobs.step[i] = step[i];
+    jobs.l0[i] = l0[i];
+    jobs.l1[i] = l1[i];
+    jobs.l2[i] = l2[i];
+  }
+  dim3 grid((unsigned)((cols + kPyrT0 - 1) / kPyrT0), (unsigned)((rows + kPyrT0 - 1) / kPyrT0), (unsigned)n_images);
+  hipLaunchKernelGGL(lk_pyramid2_kernel, grid, dim3(256), 0, st, jobs, rows, cols);
   return hipGetLastError();
 }
 

@@ -90,6 +90,11 @@ class HipCorrelationEngine:
         self._chk(self.lib.lk_set_image_device(self._h, slot, C.c_void_p(dev_ptr), rows, cols,
                                                cols if step is None else step))
 
+    def set_image_pair_device(self, und_ptr, def_ptr, rows, cols, und_step=None, def_step=None):
+        self._chk(self.lib.lk_set_image_pair_device(self._h, C.c_void_p(und_ptr), cols if und_step is None else und_step,
+                                                    C.c_void_p(def_ptr), cols if def_step is None else def_step,
+                                                    rows, cols))
+
     def set_undeformed_image(self, px):
         self.set_image(IMG_UND, px)
 

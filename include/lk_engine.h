@@ -129,6 +129,10 @@ int lk_synchronize(lk_engine *e);
 int lk_set_image(lk_engine *e, int slot, const uint8_t *host_pixels, int rows, int cols, int step);
 /* same, pixels already in this device's memory (used after an RCCL broadcast) */
 int lk_set_image_device(lk_engine *e, int slot, const void *device_pixels, int rows, int cols, int step);
+/* CudaClass::resetImagePyramids(und, def, ...) (cuda_class.cu:475-519): both frames of a pair,
+ * already in this device's memory, uploaded and reduced in one launch */
+int lk_set_image_pair_device(lk_engine *e, const void *und_pixels, int und_step, const void *def_pixels,
+                             int def_step, int rows, int cols);
 /* CorrelationClass::set_und_image_from_def / set_def_image_from_nxt
  * (correlation_class.cpp:53-61), CudaClass::makeUndPyramidFromDef / makeDefPyramidFromNxt
  * (cuda_class.cu:561-567): pointer rotation, no copies */

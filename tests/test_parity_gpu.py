@@ -180,7 +180,21 @@ def test_pyramid_from_device_frames_bit_exact(oracle):
         assert hip.hipMemcpy(dev, host.ctypes.data_as(ctypes.c_void_p), host.size, 1) == 0
         e.set_image_device(ca.IMG_DEF, dev.value + shift, shape[0], shape[1], step)
         e.synchronize()
-        assert hip.hipFree(dev) == 0
+        # the pair entry point (both frames in one launch) must give the same bytes in both slots
+        e2 = ca.HipCorrelationEngine(py_stop=stop)
+        img2 = np.ascontiguousarray(img[::-1])
+        dev2 = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(dev2), img2.size) == 0
+        assert hip.hipMemcpy(dev2, img2.ctypes.data_as(ctypes.c_void_p), img2.size, 1) == 0
+        e2.set_image_pair_device(dev2.value, dev.value + shift, shape[0], shape[1], shape[1], step)
+        e2.synchronize()
+        o2 = oracle.Oracle(py_stop=stop)
+        o2.set_image(0, img2)
+        for lvl in range(0, stop + 1):
+            assert np.array_equal(e2.get_pyramid_level(ca.IMG_DEF, lvl), e.get_pyramid_level(ca.IMG_DEF, lvl))
+            assert np.array_equal(e2.get_pyramid_level(ca.IMG_UND, lvl), o2.get_level(0, lvl))
+        e2.close()
+        assert hip.hipFree(dev) == 0 and hip.hipFree(dev2) == 0
         o = oracle.Oracle(py_stop=stop)
         o.set_image(1, img)
         for lvl in range(0, stop + 1):
