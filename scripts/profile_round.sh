@@ -9,8 +9,9 @@ tag=${1:-r01}
 out=gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o bench -- python3 bench.py --steps 20 --warmup 3 > "$out/${tag}_bench.json" 2> "$out/bench.err"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o bench -- python3 bench.py --steps 100 --warmup 10 > "$out/${tag}_bench.json" 2> "$out/bench.err"
 find "$out/trace" -name '*kernel_stats.csv' -exec cp {} "$out/${tag}_bench_kernel_stats.csv" \;
+find "$out/trace" -name '*kernel_trace.csv' -delete   # tens of MB; the stats are what is kept
 echo "bench traced" >> "$out/progress.log"
 # derived counters take a whole pass each on gfx950 ("exceeds the capabilities of the hardware" otherwise)
 i=0
