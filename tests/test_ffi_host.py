@@ -68,12 +68,12 @@ def test_missing_library_is_an_import_error(tmp_path):
 
 
 def test_product_never_touches_the_oracle():
-    """The oracle is test infrastructure: nothing under correlation_amd/, include/ or bench.py's
-    product leg may import, link or open it."""
-    for base in ("correlation_amd", "include"):
+    """The oracle is test infrastructure: nothing under correlation_amd/, include/, scripts/ or
+    bench.py's product leg may import, link or open it."""
+    for base in ("correlation_amd", "include", "scripts"):
         for dp, _, fs in os.walk(os.path.join(ROOT, base)):
             for f in fs:
-                if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", ".sh")):
                     txt = open(os.path.join(dp, f)).read()
                     assert "lk_oracle" not in txt and "lko_" not in txt and "oracle/" not in txt, \
                         os.path.join(dp, f)

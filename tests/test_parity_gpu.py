@@ -12,7 +12,7 @@ What is bit-exact and what cannot be
                               `number_of_threads` (default 20, defines.hpp:10), whose only
                               numerical effect is how the sums are split
                               (correlation_class.cpp:169-186,:253-275).  Measured on config C2
-                              (scripts/parity_noise.py, 3000 sectors): oracle(T=8) vs
+                              (tests/tools/parity_noise.py, 3000 sectors): oracle(T=8) vs
                               oracle(T=1) p50/p99/max = 3.6e-7 / 1.1e-4 / 1.3e-4 px on p0,p1
                               and 3e-7 / 2.6e-4 / 6e-4 relative on chi; the engine vs
                               oracle(T=1) shows the same distribution (3.6e-7 / 1.1e-4 /
@@ -22,7 +22,7 @@ What is bit-exact and what cannot be
   reference tree and its SIMD reduction order is build-dependent), whose own rounding error
   moves the results MORE than the thread split does: an oracle that solves the very same
   float32 systems exactly (float64 elimination) lands as far from the QR oracle (median
-  4e-6 px, scripts/solver_noise.py) as any other backward-stable solver does.  The engine
+  4e-6 px, tests/tools/solver_noise.py) as any other backward-stable solver does.  The engine
   uses a root-free Cholesky (U^T D U) - the reference's own CUDA path uses cuSOLVER's
   Cholesky (cuda_solver.cu:120-149) - so it can be as close to the QR oracle as an exact
   solver is, not closer.

@@ -1,5 +1,5 @@
 import os, sys, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import correlation_amd as ca
 from oracle import lk_oracle as lo
 und, dfm = ca.speckle.speckle_pair(2048, 2048, seed=7)
