@@ -1337,11 +1337,11 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
                                                              GROUP == 16 ? width : 0);
     if (active) {
       Cold k = cold.load(cold_slot);
-      float evaluated[6]; // the parameters this evaluation ran at, in level-0 scale
+      float evaluated[6]; // the parameters this evaluation ran at (rescaled to level 0 only if the sector ends here)
 #pragma unroll
       for (int i = 0; i < 6; ++i)
         evaluated[i] = p[i];
-      translate<P>(evaluated, k.level, 0);
+      const int evaluated_level = k.level;
       ++k.n_evals;
       k.n_sample_evals += (uint32_t)c.n;
       bool level_end = false, iter_start = false, finished = false, handed = false;
@@ -1421,8 +1421,10 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
           enter_level(k);
         }
       }
-      if (finished)
+      if (finished) {
+        translate<P>(evaluated, evaluated_level, 0);
         finish_sector(k, evaluated);
+      }
       else if (handed)
         hand_over(k);
       else if (STARVED && a.eval_cap > 0 && ++steps >= a.eval_cap)
