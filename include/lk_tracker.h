@@ -120,7 +120,8 @@ int lk_sequence_frame(lk_engine *e, lk_tracker *t, int frame, const char *und_na
                       int *stop_sequence);
 
 /* image source of lk_sequence_run: returns the level-0 pixels of frame `index` (monochrome u8,
- * *step bytes per row); the buffer must stay valid until the next call for index + 1 returns.
+ * *step bytes per row); the buffer of frame i must stay valid until the call for frame i + 2
+ * returns (two frames are in flight).
  * Called from a helper thread for the prefetch of frame k + 2 (manager_class.cpp:1438-1447). */
 typedef const uint8_t *(*lk_frame_provider)(void *user, int index, int *rows, int *cols, int *step,
                                             const char **name);

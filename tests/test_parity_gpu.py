@@ -1049,3 +1049,36 @@ def test_configs_4_and_5_full_size_properties(size, hs, n0, stop, sectors):
     rp = part.correlate_all(np.zeros(6, np.float32))
     part.close()
     assert rp.tobytes() == rf[first:first + count].tobytes()
+
+
+@pytest.mark.gpu
+def test_cpp_example_tracks_a_pgm_sequence(tmp_path):
+    """examples/track_sequence.cpp - a plain C++ program on the C ABI (lk_create, lk_tracker_*,
+    lk_sequence_run with its own PGM frame provider, lk_tracker_report) - must write the report
+    the Python-driven frame loop writes for the same frames."""
+    import subprocess
+    from correlation_amd import tracker as tk
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "track_sequence"
+    cmd = ["g++", "-std=c++17", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "track_sequence.cpp"),
+           "-L" + os.path.join(root, "correlation_amd"), "-llk_engine", "-Wl,-rpath," + os.path.join(root, "correlation_amd"),
+           "-o", str(exe)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    frames = ca.speckle.speckle_sequence(256, 256, 4, velocity=(0.9, -0.5), dilation=4e-4, seed=3)
+    paths = []
+    for i, f in enumerate(frames):
+        p = tmp_path / f"f{i}.pgm"
+        p.write_bytes(b"P5\n256 256\n255\n" + f.tobytes())
+        paths.append(str(p))
+    for mode, deformation, ref in (("eulerian", tk.DEF_EULERIAN, tk.REF_FIRST), ("lagrangian", tk.DEF_LAGRANGIAN, tk.REF_PREVIOUS)):
+        out = tmp_path / f"report_{mode}.csv"
+        r = subprocess.run([str(exe), str(out), mode, "4", "3"] + paths, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "3 pairs, 12 sectors" in r.stdout
+        e = ca.HipCorrelationEngine()
+        t = tk.SequenceTracker(ca.FM_UVUXUYVXVY, tk.DOMAIN_RECT, deformation, ref, lib=e.lib)
+        t.set_rect_domain(24.0, 24.0, 231.0, 231.0, 127.5, 127.5, 4, 3)
+        assert tk.run_sequence(e, t, frames, paths) == 3
+        assert out.read_text() == t.report()
+        e.close(), t.close()
