@@ -101,3 +101,15 @@ def test_cuda_class_adapter_compiles_against_reference_headers(tmp_path):
                         "-I", "/root/reference", "-c", str(src), "-o", str(tmp_path / "a.o")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_cpp_example_builds_against_the_c_abi(engine_lib, tmp_path):
+    """examples/track_sequence.cpp uses nothing but include/*.h and liblk_engine.so."""
+    import subprocess
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "track_sequence.cpp"), "-L" + os.path.join(ROOT, "correlation_amd"),
+           "-llk_engine", "-Wl,-rpath," + os.path.join(ROOT, "correlation_amd"), "-o", str(tmp_path / "track_sequence")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(tmp_path / "track_sequence")], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
