@@ -94,7 +94,7 @@ def other_configs(ca):
         return m
 
     try:  # the opt-in separable evaluation of the same bicubic surface (include/lk_engine.h)
-        from correlation_amd.workload import C2
+        from correlation_amd.workload import C2, C4, C4B, C5, shard_range
         und, dfm = ca.speckle.speckle_pair(C2.size, C2.size, p=C2.truth, seed=7)
         res = {}
         for label, interp in (("reference_order", ca.IM_BICUBIC), ("separable", ca.IM_BICUBIC_SEPARABLE)):
@@ -164,11 +164,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sectors", type=int, default=10000)
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--workload", default="C2", choices=["C2", "C4", "C4B", "C5"],
+                    help="C2 (default, the headline: weak scaling, every rank its own 10k-sector grid); "
+                         "C4 / C4B / C5: ONE pair of that config with its sector grid sharded over the ranks "
+                         "(strong scaling; frame broadcast + record all-gather per step)")
     args = ap.parse_args()
 
     import torch
     import correlation_amd as ca
-    from correlation_amd.workload import C2
+    from correlation_amd.workload import C2, C4, C4B, C5, shard_range
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -185,8 +189,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL
 
-    wl = C2
-    und, dfm = ca.speckle.speckle_pair(wl.size, wl.size, p=wl.truth, seed=7)
+    wl = {"C2": C2, "C4": C4, "C4B": C4B, "C5": C5}[args.workload]
+    strong = args.workload != "C2"
+    if wl.size > 2048:   # 8192^2: rendered on the GPU (every rank renders; only rank 0's def frame is used)
+        und, dfm = ca.speckle.speckle_pair(wl.size, wl.size, p=(1.3, -0.7, 0.0005, 0.0, 0.0, -0.00025), seed=13,
+                                           device=f"cuda:{local_rank}")
+    else:
+        und, dfm = ca.speckle.speckle_pair(wl.size, wl.size, p=wl.truth, seed=7)
     dev = torch.device("cuda", local_rank)
     d_und = torch.from_numpy(und).to(dev)
     d_def = torch.from_numpy(dfm).to(dev) if rank == 0 else torch.empty_like(d_und)
@@ -199,19 +208,23 @@ def main():
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     e.set_stream(stream.cuda_stream)
-    # weak scaling: rank r correlates the C2 grid shifted by r px (same sector size, distinct ROIs)
-    e.set_rect_grid(wl.x_begin + rank, wl.x_begin + rank, wl.x_end + rank - 8 * (world > 1),
-                    wl.x_end + rank - 8 * (world > 1), wl.hs, wl.vs)
+    if strong:   # one grid, contiguous blocks of the sector index per rank
+        first, count = shard_range(wl.hs * wl.vs, rank, world)
+        e.set_rect_grid(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, wl.hs, wl.vs, first, count)
+    else:        # weak scaling: rank r correlates the C2 grid shifted by r px (same sector size, distinct ROIs)
+        e.set_rect_grid(wl.x_begin + rank, wl.x_begin + rank, wl.x_end + rank - 8 * (world > 1),
+                        wl.x_end + rank - 8 * (world > 1), wl.hs, wl.vs)
     e.commit_sectors()
     S = e.n_sectors
+    S_cap = (wl.hs * wl.vs + world - 1) // world if strong else S   # equal all-gather blocks
     n0 = e.sector_info(0)[0]
     d_guess = torch.zeros((S, 6), dtype=torch.float32, device=dev)
     # double buffers: the broadcast of frame k+1 and the gather of the records of frame k
     # run on RCCL's streams while frame k / k+1 is being solved (the reference prefetches the
     # next frame the same way, manager_class.cpp:1438-1447)
     d_defs = [d_def, d_def.clone()]
-    d_ress = [torch.empty((S, 48), dtype=torch.uint8, device=dev) for _ in range(2)]
-    d_alls = [torch.empty((world * S, 48), dtype=torch.uint8, device=dev) for _ in range(2)] if use_dist else None
+    d_ress = [torch.zeros((S_cap, 48), dtype=torch.uint8, device=dev) for _ in range(2)]
+    d_alls = [torch.empty((world * S_cap, 48), dtype=torch.uint8, device=dev) for _ in range(2)] if use_dist else None
     pending = {"bcast": None, "gather": [None, None], "k": 0}
 
     def prefetch(k):  # frame k -> d_defs[k % 2], over RCCL / xGMI
@@ -272,7 +285,7 @@ def main():
     dt_max = float(tmax.item())
     total_pit = float(pit.item()) * args.steps
 
-    res = d_ress[0].cpu().numpy().view(ca.RESULT_DTYPE).reshape(-1)
+    res = d_ress[0][:S].cpu().numpy().view(ca.RESULT_DTYPE).reshape(-1)
     if rank == 0:
         value = total_pit / dt_max
         achieved = st["algorithmic_bytes"] / (solve_avg_ms * 1e-3) / 1e9
@@ -293,26 +306,30 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt_max / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl.name, "sectors_per_gpu": S, "samples_per_sector": n0,
+            "config": {"workload": wl.name, "sectors_per_gpu": S, "sectors_total": wl.hs * wl.vs if strong else S * world,
+                       "samples_per_sector": n0,
                        "interpolation": "bicubic", "parallelism": f"sectors sharded x{world}",
                        "step": "pyramid(und)+pyramid(def)+solve, inputs resident in HBM"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "lk_solve_kernel<fm_UVUxUyVxVy, im_bicubic> (32-lane groups, 2 sectors per wavefront)",
+                         "kernel": ("lk_solve_kernel<fm_UVUxUyVxVy, im_bicubic> (32-lane groups, 2 sectors per wavefront)"
+                                    if not strong else
+                                    "lk_solve_kernel<fm_UVUxUyVxVy, im_bicubic>: all launches of one solve "
+                                    "(one-lane starved-level kernel, finisher, 16-lane groups)"),
                          "kernel_ms": solve_avg_ms,
                          "algorithmic_bytes_per_launch": st["algorithmic_bytes"]},
-            "per_pair": {"sectors_per_s": S * world * args.steps / dt_max,
+            "per_pair": {"sectors_per_s": (wl.hs * wl.vs if strong else S * world) * args.steps / dt_max,
                          "evaluations": st["evaluations"], "sample_evaluations": st["sample_evaluations"],
                          "point_iterations": st["point_iterations"],
                          "mean_point_iterations_per_sector": st["point_iterations"] / S,
                          "error_free_fraction": float((res["error_code"] == 0).mean()),
                          "last_solve_ms": st["solve_ms"], "last_pyramid_ms": st["pyramid_ms"]},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not strong:
             base, nsec = cpu_baseline(wl, und, dfm, args.cpu_sectors)
             pit_per_sector = st["point_iterations"] / S
             rate_mt, dt_mt, thr_mt, res_mt = base["all_cores"]
@@ -332,7 +349,7 @@ def main():
                 "max_rel_dchi": float((np.abs(res["chi"][xs] - res_1["chi"]) / np.abs(res_1["chi"])).max()),
                 "iterations_equal_fraction": float((res["iterations"][xs] == res_1["iterations"]).mean()),
             }
-        if world == 1 and not args.no_other_configs and not use_dist:
+        if world == 1 and not args.no_other_configs and not use_dist and not strong:
             e.close()
             line["other_configs"] = other_configs(ca)
         print(json.dumps(line))
