@@ -293,8 +293,9 @@ def main():
         # WRITE_SIZE, calibrated; profiles/r01_pmc_traffic.txt) - a profile, not a live counter
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-                traffic = json.load(f)["solve_kernel_hbm_bytes_per_launch_C2"] / (solve_avg_ms * 1e-3) / 1e9
+            if not strong:   # the PMC profile is of the C2 launch
+                with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                    traffic = json.load(f)["solve_kernel_hbm_bytes_per_launch_C2"] / (solve_avg_ms * 1e-3) / 1e9
         except Exception:
             pass
         line = {
