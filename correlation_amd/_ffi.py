@@ -110,6 +110,11 @@ SYMBOLS = {
     "lk_tracker_report": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "lk_sequence_frame": (C.c_int, [_P, _P, C.c_int, C.c_char_p, C.c_char_p, _I]),
     "lk_sequence_run": (C.c_int, [_P, _P, C.c_int, _P, _P, _I]),
+    "lk_roi_rect_grid": (C.c_int, [C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _I, _I, _I]),
+    "lk_roi_annular_points": (C.c_int64, [C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
+                                          _F, C.c_int64]),
+    "lk_roi_blob_points": (C.c_int64, [_F, C.c_int, _F, C.c_int64]),
+    "lk_roi_decimate": (C.c_int, [_F, C.c_int, C.c_int, _F]),
     "lk_load_pgm": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), _I, _I]),
     "lk_free_image": (None, [C.POINTER(C.c_uint8)]),
 }

@@ -647,6 +647,57 @@ int lk_sequence_run(lk_engine *e, lk_tracker *t, int n_frames, lk_frame_provider
   return rc;
 }
 
+// ------------------------------------------------------------------------------------
+// ROI -> sample lists without an engine (host code of lk_roi.hpp; what lk_set_sector_* use)
+// ------------------------------------------------------------------------------------
+static int64_t copy_out(const std::vector<float> &v, float *xy, int64_t cap) {
+  const int64_t n = (int64_t)(v.size() / 2);
+  if (xy && cap > 0)
+    std::memcpy(xy, v.data(), 2 * sizeof(float) * (size_t)(n < cap ? n : cap));
+  return n;
+}
+
+int lk_roi_rect_grid(float x_begin, float y_begin, float x_end, float y_end, int hs, int vs, int *xdim, int *ydim,
+                     int *centers_xy) {
+  if (hs < 1 || vs < 1)
+    return LK_ERROR_BAD_DOMAIN;
+  lkroi::RectGrid g = lkroi::rect_grid(x_begin, y_begin, x_end, y_end, hs, vs);
+  if (xdim)
+    *xdim = g.xdim;
+  if (ydim)
+    *ydim = g.ydim;
+  if (centers_xy)
+    for (int i = 0; i < hs; ++i)
+      for (int j = 0; j < vs; ++j) {
+        centers_xy[2 * (i * vs + j)] = g.cx[i];
+        centers_xy[2 * (i * vs + j) + 1] = g.cy[j];
+      }
+  return LK_ERROR_NONE;
+}
+
+int64_t lk_roi_annular_points(float r, float dr, float a, float da, float cx, float cy, int as, float *xy,
+                              int64_t cap) {
+  std::vector<float> v;
+  if (!lkroi::annular_points(r, dr, a, da, cx, cy, as, v))
+    return -1;
+  return copy_out(v, xy, cap);
+}
+
+int64_t lk_roi_blob_points(const float *contour_xy, int n_vertices, float *xy, int64_t cap) {
+  std::vector<float> v;
+  if (!contour_xy || !lkroi::BlobPolygon::inside_points(contour_xy, n_vertices, v))
+    return -1;
+  return copy_out(v, xy, cap);
+}
+
+int lk_roi_decimate(const float *xy, int n, int level_delta, float *out) {
+  std::vector<float> v;
+  const int kept = lkroi::decimate(xy, n, level_delta, v);
+  if (out)
+    std::memcpy(out, v.data(), 2 * sizeof(float) * (size_t)kept);
+  return kept;
+}
+
 int lk_load_pgm(const char *path, uint8_t **pixels, int *rows, int *cols) {
   if (!path || !pixels || !rows || !cols)
     return LK_ERROR_BAD_DOMAIN;

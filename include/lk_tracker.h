@@ -130,6 +130,21 @@ typedef const uint8_t *(*lk_frame_provider)(void *user, int index, int *rows, in
 int lk_sequence_run(lk_engine *e, lk_tracker *t, int n_frames, lk_frame_provider provider, void *user,
                     int *pairs_done);
 
+/* ---- ROI -> sample lists, host only (the code behind lk_set_rect_grid / lk_set_sector_annular /
+ * lk_set_sector_blob / lk_commit_sectors; usable without a device, e.g. to size buffers or to
+ * draw overlays) ------------------------------------------------------------------------------ */
+/* sector geometry of a rectangular domain (manager_class.cpp:276-310): half sizes and hs*vs
+ * integer centres in iSector = i*vs + j order */
+int lk_roi_rect_grid(float x_begin, float y_begin, float x_end, float y_end, int hs, int vs, int *xdim, int *ydim,
+                     int *centers_xy);
+/* get_inside_points_annularDomain (manager_class.cpp:816-940); returns the count (may exceed cap) */
+int64_t lk_roi_annular_points(float r, float dr, float a, float da, float cx, float cy, int as, float *xy,
+                              int64_t cap);
+/* polygonBlob_class (polygon_class.cpp:224-429); -1 for a self-intersecting contour */
+int64_t lk_roi_blob_points(const float *contour_xy, int n_vertices, float *xy, int64_t cap);
+/* per-level decimation (pyramid_class.cpp:289-323); returns the count written */
+int lk_roi_decimate(const float *xy, int n, int level_delta, float *out);
+
 /* ---- image ingest ------------------------------------------------------------------------ */
 /* binary PGM (P5, maxval <= 255) reader for headless runs; *pixels is malloc'ed (free with
  * lk_free_image) */

@@ -113,3 +113,49 @@ def test_cpp_example_builds_against_the_c_abi(engine_lib, tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(tmp_path / "track_sequence")], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr
+
+
+def test_host_roi_code_equals_oracle_and_reference_goldens(engine_lib, oracle):
+    """The product's ROI -> sample-list code (lk_roi.hpp, behind lk_set_sector_* and
+    lk_commit_sectors) through its host-only entry points: rectangular grid geometry, annular
+    sectors, blob rasterisation (incl. the reference's own polygonBlob_class outputs) and the
+    per-level decimation, bit for bit."""
+    L = engine_lib
+    # rectangular grids
+    for args in ((24.0, 24.0, 2023.0, 2023.0, 100, 100), (24.0, 24.0, 2023.0, 2023.0, 224, 224), (3.5, 7.25, 490.0, 300.5, 7, 5)):
+        xd, yd = C.c_int(), C.c_int()
+        cen = np.zeros((args[4] * args[5], 2), np.int32)
+        assert L.lk_roi_rect_grid(*args, C.byref(xd), C.byref(yd), cen.ctypes.data_as(C.POINTER(C.c_int))) == 0
+        wxd, wyd, wcen = oracle.rect_sector_geometry(*args)
+        assert (xd.value, yd.value) == (wxd, wyd) and np.array_equal(cen, wcen)
+    # annular sectors
+    for args in ((30.0, 24.0, 0.4, 0.9, 128.0, 126.0, 7), (600.0, 150.0, 1.1, 0.19634954, 2048.0, 2048.0, 32),
+                 (10.0, 40.0, 0.0, 6.2831855, 64.0, 64.0, 1)):
+        n = L.lk_roi_annular_points(*args, None, 0)
+        got = np.zeros((max(n, 1), 2), np.float32)
+        assert L.lk_roi_annular_points(*args, _ffi.fptr(got), n) == n
+        want = oracle.annular_points(*args)
+        assert n == len(want) and got[:n].tobytes() == want.tobytes()
+    # blobs: the reference's own polygonBlob_class outputs (tests/golden/ref_blob.npz)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_blob.npz"))
+    cases = sorted({k[:-len("_contour")] for k in g.files if k.endswith("_contour")})
+    assert len(cases) >= 4
+    for c in cases:
+        contour, count = np.ascontiguousarray(g[c + "_contour"], np.float32), int(g[c + "_count"])
+        n = L.lk_roi_blob_points(_ffi.fptr(contour), len(contour), None, 0)
+        if count < 0:            # the reference rejects the contour (self-intersecting loop)
+            assert n == -1, c
+            continue
+        want = g[c + "_pts"]
+        got = np.zeros((max(n, 1), 2), np.float32)
+        L.lk_roi_blob_points(_ffi.fptr(contour), len(contour), _ffi.fptr(got), n)
+        assert n == count and got[:n].tobytes() == np.ascontiguousarray(want, np.float32).reshape(-1, 2)[:n].tobytes(), c
+    # decimation
+    rng = np.random.default_rng(4)
+    pts = (rng.random((500, 2)) * 64).astype(np.float32)
+    pts[::3] = np.round(pts[::3])
+    for delta in (1, 2):
+        out = np.zeros_like(pts)
+        k = L.lk_roi_decimate(_ffi.fptr(pts), len(pts), delta, _ffi.fptr(out))
+        want = oracle.decimate(pts, delta)
+        assert k == len(want) and out[:k].tobytes() == want.tobytes()
