@@ -141,7 +141,7 @@ def test_host_roi_code_equals_oracle_and_reference_goldens(engine_lib, oracle):
     cases = sorted({k[:-len("_contour")] for k in g.files if k.endswith("_contour")})
     assert len(cases) >= 4
     for c in cases:
-        contour, count = np.ascontiguousarray(g[c + "_contour"], np.float32), int(g[c + "_count"])
+        contour, count = np.ascontiguousarray(g[c + "_contour"], np.float32), int(np.asarray(g[c + "_count"]).reshape(-1)[0])
         n = L.lk_roi_blob_points(_ffi.fptr(contour), len(contour), None, 0)
         if count < 0:            # the reference rejects the contour (self-intersecting loop)
             assert n == -1, c
