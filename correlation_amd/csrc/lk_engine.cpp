@@ -1368,7 +1368,7 @@ int lk_damped_solve(lk_engine *e, int n, const float *A, const float *b, float l
   }
   h[42] = lambda;
   h[43] = scaling;
-  h[44] = reference_solver ? 1.f : 0.f;
+  h[44] = (float)reference_solver; // 0: fast path, 1: the restated QR, 2: the same QR spread over a 16-lane row
   HIPCHK(hipMemcpyAsync(e->d_scratch.p, h, sizeof(h), hipMemcpyHostToDevice, e->stream));
   HIPCHK(lk_launch_solve_only(n, e->d_scratch.p, e->d_scratch.p + 48, e->stream));
   float o[6];

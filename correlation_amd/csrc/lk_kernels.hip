@@ -800,10 +800,220 @@ __device__ __forceinline__ void colpiv_qr_solve(float (&M)[N * N], const float (
 }
 
 
+// The same factorisation and solve, operation for operation, spread over the 16 lanes of a row
+// that all hold the same inputs (the finisher of starved levels): lane j owns COLUMN j - its
+// six entries, its norms and its current position in the pivot order - instead of every lane
+// carrying the whole matrix through ~3000 instructions.  Column swaps become exchanges of
+// positions (no data moves); the pivot scan runs on the norms gathered by position, in the
+// reference's order (first strictly larger wins, NaN never wins); the Householder vector, tau
+// and the triangular factor travel by ds_bpermute from the lane that owns them.  Every
+// arithmetic operation is the one colpiv_qr_solve performs, on the same operands, in the same
+// order, so the step is bit-identical (tests: lk_damped_solve with reference_solver = 2 against 1
+// on random, rank-deficient and non-finite systems; the finisher's end-to-end bit identity).
+template <int N>
+__device__ __forceinline__ void colpiv_qr_solve_row16(const float (&M)[N * N], const float (&bin)[N],
+                                                      float (&x)[N]) {
+  const int lane = (int)threadIdx.x & 63, me = lane & 15, row_base = lane & ~15;
+  auto from = [&](float v, int src) { return __shfl(v, row_base | src, 64); }; // lane `src` of the own row
+  // my column (lanes >= N carry a dummy column that is never selected)
+  float col[N];
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < N; ++c)
+      v = me == c ? M[c * N + r] : v;
+    col[r] = v;
+  }
+  int pos = me;      // position of my column in the pivot order
+  int owner[N];      // replicated: lane that owns the column at each position
+#pragma unroll
+  for (int q = 0; q < N; ++q)
+    owner[q] = q;
+  const float eps = FLT_EPSILON;
+  float s0 = 0.f;
+#pragma unroll
+  for (int r = 0; r < N; ++r)
+    s0 += col[r] * col[r];
+  float normD = __builtin_sqrtf(s0), normU = normD;
+  float maxn = 0.f;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const float nk = from(normU, k);
+    if (nk > maxn)
+      maxn = nk;
+  }
+  const float threshold_helper = (maxn * eps) * (maxn * eps) / (float)N;
+  const float norm_downdate_threshold = __builtin_sqrtf(eps);
+  int nonzero_pivots = N;
+  float hc[N], vk[N][N]; // replicated: tau of step k and its Householder vector (rows r > k)
+  int trans[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    // pivot scan over positions k..N-1, in order
+    int big = k;
+    float bigv = from(normU, owner[k]);
+#pragma unroll
+    for (int j = k + 1; j < N; ++j) {
+      const float nj = from(normU, owner[j]);
+      if (nj > bigv) {
+        bigv = nj;
+        big = j;
+      }
+    }
+    const float big_sq = bigv * bigv;
+    if (nonzero_pivots == N && big_sq < threshold_helper * (float)(N - k))
+      nonzero_pivots = k;
+    trans[k] = big;
+    // exchange positions k and big
+    int owner_big = owner[k];
+#pragma unroll
+    for (int j = k + 1; j < N; ++j)
+      owner_big = big == j ? owner[j] : owner_big;
+    const int owner_k = owner[k];
+#pragma unroll
+    for (int j = k + 1; j < N; ++j)
+      owner[j] = big == j ? owner_k : owner[j];
+    owner[k] = owner_big;
+    if (big != k) {
+      if (me == owner_big)
+        pos = k;
+      else if (me == owner_k)
+        pos = big;
+    }
+    // Householder of the column at position k - every lane works on its own column, the
+    // pivot's result is what gets used
+    float tailSq = 0.f;
+#pragma unroll
+    for (int r = k + 1; r < N; ++r)
+      tailSq += col[r] * col[r];
+    const float c0 = col[k];
+    float beta, tau, ess[N];
+    if (tailSq <= FLT_MIN) {
+      tau = 0.f;
+      beta = c0;
+#pragma unroll
+      for (int r = k + 1; r < N; ++r)
+        ess[r] = 0.f;
+    } else {
+      beta = __builtin_sqrtf(c0 * c0 + tailSq);
+      if (c0 >= 0.f)
+        beta = -beta;
+      const float den = c0 - beta;
+#pragma unroll
+      for (int r = k + 1; r < N; ++r)
+        ess[r] = col[r] / den;
+      tau = (beta - c0) / beta;
+    }
+    const int pl = owner[k];
+    const bool i_am_pivot = me == pl;
+    hc[k] = from(tau, pl);
+#pragma unroll
+    for (int r = k + 1; r < N; ++r)
+      vk[k][r] = from(ess[r], pl);
+    if (i_am_pivot) {
+      col[k] = beta;
+#pragma unroll
+      for (int r = k + 1; r < N; ++r)
+        col[r] = ess[r];
+    }
+    const bool later = pos > k && me < N; // my column is still to the right of the pivot
+    if (N - k > 1 && hc[k] != 0.f) {
+      float tmp = 0.f;
+#pragma unroll
+      for (int r = k + 1; r < N; ++r)
+        tmp += vk[k][r] * col[r];
+      tmp += col[k];
+      const float ck = col[k] - hc[k] * tmp;
+      float cr[N];
+#pragma unroll
+      for (int r = k + 1; r < N; ++r)
+        cr[r] = col[r] - tmp * (hc[k] * vk[k][r]);
+      if (later) {
+        col[k] = ck;
+#pragma unroll
+        for (int r = k + 1; r < N; ++r)
+          col[r] = cr[r];
+      }
+    }
+    if (later && normU != 0.f) { // norm down-dating of my column
+      float temp = __builtin_fabsf(col[k]) / normU;
+      temp = (1.f + temp) * (1.f - temp);
+      temp = temp < 0.f ? 0.f : temp;
+      const float ratio = normU / normD;
+      const float temp2 = temp * (ratio * ratio);
+      if (temp2 <= norm_downdate_threshold) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = k + 1; r < N; ++r)
+          s += col[r] * col[r];
+        normD = __builtin_sqrtf(s);
+        normU = normD;
+      } else {
+        normU *= __builtin_sqrtf(temp);
+      }
+    }
+  }
+  if (nonzero_pivots == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      x[i] = 0.f;
+    return;
+  }
+  float cv[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    cv[i] = bin[i];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (k < nonzero_pivots) {
+      if (N - k == 1) {
+        cv[k] *= 1.f - hc[k];
+      } else if (hc[k] != 0.f) {
+        float tmp = 0.f;
+#pragma unroll
+        for (int r = k + 1; r < N; ++r)
+          tmp += vk[k][r] * cv[r];
+        tmp += cv[k];
+        cv[k] -= hc[k] * tmp;
+#pragma unroll
+        for (int r = k + 1; r < N; ++r)
+          cv[r] -= tmp * (hc[k] * vk[k][r]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    if (i < nonzero_pivots) {
+      cv[i] = cv[i] / from(col[i], owner[i]);
+#pragma unroll
+      for (int r = 0; r < i; ++r)
+        cv[r] -= cv[i] * from(col[r], owner[i]);
+    } else {
+      cv[i] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    x[i] = cv[i];
+#pragma unroll
+  for (int k = N - 1; k >= 0; --k) {
+#pragma unroll
+    for (int j = k + 1; j < N; ++j)
+      if (trans[k] == j) {
+        const float t = x[k];
+        x[k] = x[j];
+        x[j] = t;
+      }
+  }
+}
+
+
 // S holds the raw sums (upper triangle row-major, b, chi); p += dp.
 template <int P, bool SAFE>
 __device__ __forceinline__ void damped_step(const Sums<P> &S, float lambda, float scaling,
-                                            float (&p)[6], bool starved, float *dp_out = nullptr) {
+                                            float (&p)[6], bool starved, float *dp_out = nullptr,
+                                            bool row16 = false) {
   // U[i][j], i <= j: starts as the scaled, damped upper triangle of A
   float U[P][P], d[P], inv_d[P], y[P], x[P];
   int idx = 0;
@@ -827,6 +1037,7 @@ __device__ __forceinline__ void damped_step(const Sums<P> &S, float lambda, floa
   // A starved level (see evaluate<>) always takes the reference's solver: its sums are
   // bit-identical to the reference's, so the whole trajectory is.
   bool well_conditioned = !starved;
+  if (!(SAFE && starved)) // (a starved level goes straight to the reference's solver)
 #pragma unroll
   for (int j = 0; j < P; ++j) {
     float w[P > 1 ? P : 1];
@@ -885,7 +1096,10 @@ __device__ __forceinline__ void damped_step(const Sums<P> &S, float lambda, floa
         M[p2 * P + p1] = a;
       }
     }
-    colpiv_qr_solve<P>(M, b, x);
+    if (row16) // every lane of the 16-lane row holds the same system: spread the QR over them
+      colpiv_qr_solve_row16<P>(M, b, x);
+    else
+      colpiv_qr_solve<P>(M, b, x);
   }
 #pragma unroll
   for (int i = 0; i < P; ++i) {
@@ -1361,7 +1575,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
 #pragma unroll
         for (int i = 0; i < P; ++i)
           tent[i] = p[i];
-        damped_step<P, SAFE || STARVED>(S, lam_use, c.scaling, p, starved); // p += dp (compute_model_parameters)
+        damped_step<P, SAFE || STARVED>(S, lam_use, c.scaling, p, starved, nullptr, finisher); // p += dp (compute_model_parameters)
         if (phase == PH_EVAL0) {
           ++k.n_point_iters;
           k.lg_chi = chi;
@@ -1506,7 +1720,7 @@ template <int P> __global__ void lk_solve_only_kernel(const float *in, float *dp
     S.v[Sums<P>::NA + p1] = in[36 + p1];
   S.v[Sums<P>::N - 1] = 0.f;
   float p[6] = {0, 0, 0, 0, 0, 0}, dp[6] = {0, 0, 0, 0, 0, 0};
-  damped_step<P, true>(S, in[42], in[43], p, in[44] != 0.f, dp);
+  damped_step<P, true>(S, in[42], in[43], p, in[44] != 0.f, dp, in[44] == 2.f);
   if (threadIdx.x == 0 && blockIdx.x == 0)
     for (int i = 0; i < 6; ++i)
       dp_out[i] = i < P ? dp[i] : 0.f;

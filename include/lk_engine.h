@@ -236,7 +236,8 @@ int lk_sample(lk_engine *e, int slot, int level, const float *xy, int n, float *
 /* compute_model_parameters + solve (correlation_class.cpp:642-768) on the device.
  * reference_solver = 0: the engine's normal choice (root-free Cholesky, falling back to the
  * reference's pivoted QR when a pivot is small); 1: the pivoted QR always, as the solve
- * kernel does on starved pyramid levels (at most 2P samples) */
+ * kernel does on starved pyramid levels (at most 2P samples); 2: the same QR spread over a
+ * 16-lane row, as the finisher of parked sectors runs it (bit-identical to 1) */
 int lk_damped_solve(lk_engine *e, int n, const float *A_rowmajor_upper, const float *b,
                     float lambda, float scaling, int reference_solver, float *dp);
 

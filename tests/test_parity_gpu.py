@@ -1082,3 +1082,50 @@ def test_cpp_example_tracks_a_pgm_sequence(tmp_path):
         assert tk.run_sequence(e, t, frames, paths) == 3
         assert out.read_text() == t.report()
         e.close(), t.close()
+
+
+@pytest.mark.gpu
+def test_row_distributed_qr_is_bit_identical(oracle):
+    """The finisher of starved levels runs the restated Eigen QR spread over the 16 lanes of a
+    row (one column per lane, positions instead of column swaps, ds_bpermute for what the
+    pivot owns).  lk_damped_solve(reference_solver=2) drives it; every step must equal the
+    one-lane restatement (reference_solver=1) and the oracle bit for bit - on healthy systems,
+    on rank-deficient ones (fewer samples than parameters: the pivot order decides), with
+    exact zeros, ties between column norms, and non-finite entries."""
+    e = ca.HipCorrelationEngine()
+    rng = np.random.default_rng(31)
+
+    def check(A, b, lam, s, label):
+        one = e.damped_solve(A, b, np.float32(lam), np.float32(s), reference_solver=1)
+        row = e.damped_solve(A, b, np.float32(lam), np.float32(s), reference_solver=2)
+        assert one.tobytes() == row.tobytes(), (label, one, row)
+        if np.isfinite(A).all():   # (x86 and gfx950 give the default NaN different sign bits)
+            want = oracle.damped_solve(A, b, np.float32(lam), np.float32(s))
+            assert np.array_equal(np.isnan(one), np.isnan(want)), label
+            assert one[~np.isnan(one)].tobytes() == want[~np.isnan(want)].tobytes(), label
+
+    for n in (1, 2, 3, 6):
+        for m in (1, 2, 3, 4, 5, 9, 60):                      # samples: rank min(m, n)
+            for _ in range(12):
+                J = rng.standard_normal((m, n)) * rng.uniform(0.5, 20, n)
+                A = (J.T @ J).astype(np.float32)
+                b = (J.T @ rng.standard_normal(m)).astype(np.float32)
+                check(A, b, 10.0 ** rng.uniform(-9, 1), 1.0 / m, (n, m))
+    # ties and exact zeros
+    check(np.eye(6, dtype=np.float32), np.arange(6, dtype=np.float32), 0.0, 1.0, "identity")
+    check(np.zeros((6, 6), np.float32), np.ones(6, np.float32), 1e-4, 1.0, "zero matrix")
+    A = np.diag([4.0, 0.0, 9.0, 0.0, 4.0, 9.0]).astype(np.float32)
+    check(A, np.array([8, 1, 18, 1, 8, 18], np.float32), 0.0, 1.0, "semi-definite with ties")
+    A = np.ones((6, 6), np.float32)
+    check(A, np.ones(6, np.float32), 1e-9, 1.0, "rank one")
+    # non-finite input (an empty pyramid level scales by 1/0): same NaN pattern, same finite bits
+    A = (rng.standard_normal((6, 6)) ** 2).astype(np.float32)
+    A = np.triu(A) + np.triu(A, 1).T
+    for bad in (np.inf, np.nan):
+        B = A.copy()
+        B[2, 2] = bad
+        one = e.damped_solve(B, np.ones(6, np.float32), np.float32(1e-4), np.float32(1.0), reference_solver=1)
+        row = e.damped_solve(B, np.ones(6, np.float32), np.float32(1e-4), np.float32(1.0), reference_solver=2)
+        assert np.array_equal(np.isnan(one), np.isnan(row)) and np.array_equal(one[~np.isnan(one)], row[~np.isnan(row)])
+    check(A, np.ones(6, np.float32), 1e-4, np.inf, "infinite scaling")
+    e.close()
