@@ -1138,6 +1138,7 @@ static int launch_starved(lk_engine *e, LkSolveArgs &a) {
     LkSolveArgs f = a;
     f.finisher = 1;
     f.safe = 1;
+    f.align = 0; // one trip per evaluation whatever the level: rows take the next parked sector as they finish
     HIPCHK(lk_launch_solve(f, e->cfg.fitting_model, e->cfg.interpolation, 16, e->stream));
   }
   a.eval_cap = 0;
