@@ -8,8 +8,10 @@
 //               decimated list of pyramid_class.cpp:301-322).
 //   sector state center[S] (float2), guess[S][6], last_p[S][6], prev_p[S][6],
 //               result[S] (48 B, layout of CorrelationResult), stats[S][4].
-// Everything for an image pair is resident; lk_correlate_all* is one launch per size
-// class (16 lanes / 1 / 4 / 8 wavefronts per sector) on one stream.
+//   rectangular sectors have no list at all: int4 {x_first, y_first, width, n} per level.
+// Everything for an image pair is resident; lk_correlate_all* is one launch per size class
+// (16 / 32 / 64 lanes, 4 / 8 wavefronts, teams) on one stream, preceded by the one-lane kernel
+// and its finisher when the class has a starved pyramid level.
 #include "lk_device.hpp"
 #include "lk_roi.hpp"
 

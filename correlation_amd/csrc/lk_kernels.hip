@@ -1,19 +1,26 @@
 // lk_kernels.hip - hand-written CDNA4 (gfx950) kernels of the Lucas-Kanade engine.
 //
-//   lk_solve_kernel    one lane group (a 16-lane DPP row, a wavefront, or 4/8 wavefronts) owns one sector for its
-//                      whole coarse-to-fine Levenberg-Marquardt solve: warp -> bicubic
-//                      sample of the deformed image + gradient -> residual -> per-lane
-//                      accumulation of the 21+6+1 sums -> DPP wavefront reduction ->
-//                      6x6 pivoted-QR solve in registers -> accept/reject on the device.
-//                      Replaces kCorrelation + k_global_reduction +
-//                      k_build_LS_problem_in_GPU0 + cuSOLVER potrf/potrs + kScale +
-//                      kUpdateParameters and the host loop of CudaClass::correlate
-//                      (cuda_class.cu:104-473, correlationKernel.cu, kernels.cu:12-103,
-//                      cuda_solver.cu), following the CPU engine's semantics
+//   lk_solve_kernel    one lane group owns one sector for its whole coarse-to-fine
+//                      Levenberg-Marquardt solve: warp -> bicubic sample of the deformed image +
+//                      gradient -> residual -> per-lane accumulation of the 21+6+1 sums -> DPP
+//                      reduction -> 6x6 solve in registers -> accept/reject on the device.
+//                      Flavours by template: GROUP = 16 / 32 / 64 lanes, 256 / 512 threads
+//                      (+ teams of 512-thread workgroups for giant sectors); GROUP = 1, one lane per
+//                      sector in the reference's summation order with the restated Eigen QR for
+//                      starved pyramid levels; SAFE 16-lane = the finisher of that kernel's
+//                      stragglers (ordered sums by row_newbcast, QR spread over the row).
+//                      Scheduling inside a wavefront: level alignment, solo (32 lanes) and adaptive
+//                      width (16 lanes) - idle lanes join the sectors still being solved.
+//                      Replaces kCorrelation + k_global_reduction + k_build_LS_problem_in_GPU0 +
+//                      cuSOLVER potrf/potrs + kScale + kUpdateParameters and the host loop of
+//                      CudaClass::correlate (cuda_class.cu:104-473, correlationKernel.cu,
+//                      kernels.cu:12-103, cuda_solver.cu), following the CPU engine's semantics
 //                      (correlation_class.cpp:349-640).
-//   lk_pyramid_kernel  5x5 Gaussian /2 level build with the CPU engine's arithmetic
-//                      (pyramid_class.cpp:83-122); replaces k_pyramid_bw (kernels.cu:761).
-//   small utilities    initial-guess policy, sample warping, stand-alone evaluation/solve.
+//   lk_pyramid2_kernel upload copy + pyramid levels 1 and 2 of one or two frames in one launch;
+//   lk_pyramid_kernel  one further level; both with the CPU engine's arithmetic
+//                      (pyramid_class.cpp:83-122), replacing k_pyramid_bw (kernels.cu:761).
+//   small utilities    level table upload, initial-guess policy, sample warping, stand-alone
+//                      evaluation / sampling / solve (known-answer entry points).
 //
 // This translation unit is compiled with -ffp-contract=off: the reference's x86-64 builds
 // have no FMA, and per-sample values (warp, bicubic value/gradient, residual, H) are kept
