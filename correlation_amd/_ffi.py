@@ -35,7 +35,7 @@ class LkConfig(C.Structure):
 class LkStats(C.Structure):
     _fields_ = [("sectors", C.c_uint64), ("evaluations", C.c_uint64),
                 ("sample_evaluations", C.c_uint64), ("point_iterations", C.c_uint64),
-                ("algorithmic_bytes", C.c_uint64), ("solve_ms", C.c_float),
+                ("algorithmic_bytes", C.c_uint64), ("ill_conditioned_solves", C.c_uint64), ("solve_ms", C.c_float),
                 ("pyramid_ms", C.c_float)]
 
 

@@ -51,6 +51,11 @@ struct LkSolveArgs {
   // finisher (`finisher` = 1) resumes it with reference-order sums spread over 16 lanes.
   int eval_cap;
   int finisher;
+  int resume;              // 1: this launch takes its sectors, in the middle of a level, from finish_list
+  // Fast-flavour kernels hand a sector whose damped system met a bad pivot to the SAFE 16-lane
+  // kernel (resume = 1, the reference's QR) instead of zeroing that parameter's step:
+  uint32_t *ill_list;      // [S] or null
+  uint32_t *ill_count;     // [1]
   uint32_t *mid_state;    // [S][kLkMidWords]
   uint32_t *finish_list;  // [S]
   uint32_t *finish_count; // [1], zeroed before the starved-level kernel

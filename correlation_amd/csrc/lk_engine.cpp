@@ -160,6 +160,7 @@ struct lk_engine {
   DevBuf<uint32_t> d_single, d_queue;
   DevBuf<LkHandoff> d_handoff;
   DevBuf<uint32_t> d_mid, d_finish_list, d_finish_count; // stragglers of the starved-level kernel
+  DevBuf<uint32_t> d_ill_list, d_ill_count;              // sectors whose damped system met a bad pivot
   int eval_cap = 32; // evaluations a lane of the starved-level kernel spends on one sector (0: no cap)
   int team_w = 0; // workgroups per sector of the team class
   int team_min_samples = 0; // per-sector team sizing (0: every team has team_w workgroups)
@@ -257,6 +258,8 @@ void lk_destroy(lk_engine *e) {
   e->d_mid.release();
   e->d_finish_list.release();
   e->d_finish_count.release();
+  e->d_ill_list.release();
+  e->d_ill_count.release();
   e->d_scratch.release();
   e->d_warp.release();
   if (e->own_stream)
@@ -816,12 +819,16 @@ static int commit_impl(lk_engine *e, bool keep_state) {
   HIPCHK(hipMemcpy(e->d_order.p, e->h_order.data(), (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice));
   HIPCHK(e->d_single.ensure(1));
   HIPCHK(e->d_queue.ensure(8 * kNumClasses));
+  HIPCHK(hipMemset(e->d_queue.p, 0, 8 * kNumClasses * sizeof(uint32_t))); // (the SAFE pass rewinds its own queue)
   HIPCHK(e->d_handoff.ensure((size_t)S));
   bool any_starved = false;
   for (int c = 0; c < kNumClasses; ++c)
     any_starved = any_starved || e->class_starved[c];
+  HIPCHK(e->d_mid.ensure((size_t)S * kLkMidWords));
+  HIPCHK(e->d_ill_list.ensure((size_t)S));
+  HIPCHK(e->d_ill_count.ensure(1));
+  HIPCHK(hipMemset(e->d_ill_count.p, 0, sizeof(uint32_t)));
   if (any_starved) {
-    HIPCHK(e->d_mid.ensure((size_t)S * kLkMidWords));
     HIPCHK(e->d_finish_list.ensure((size_t)S));
     HIPCHK(e->d_finish_count.ensure(1));
   }
@@ -1147,6 +1154,34 @@ static int launch_starved(lk_engine *e, LkSolveArgs &a) {
   return LK_ERROR_NONE;
 }
 
+// The lane-group kernel of one class, then the SAFE 16-lane kernel for the sectors it parked
+// because a damped system met a bad pivot (the reference's rank-revealing QR decides those
+// steps; on textured images the list is empty and the second launch retires at once).
+static int launch_groups(lk_engine *e, LkSolveArgs &a, int group) {
+  static const bool ill_env = [] { const char *f = std::getenv("LK_ILL_PASS"); return f ? std::atoi(f) != 0 : true; }();
+  const bool with_ill_pass = !a.safe && ill_env;
+  if (with_ill_pass) {
+    a.mid_state = e->d_mid.p;
+    a.ill_list = e->d_ill_list.p;
+    a.ill_count = e->d_ill_count.p; // (rewound by the SAFE pass itself)
+  }
+  HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, group, e->stream));
+  if (with_ill_pass) {
+    LkSolveArgs r = a;
+    r.resume = 1;
+    r.safe = 1;
+    r.ill_list = nullptr;
+    r.ill_count = nullptr;
+    r.finish_list = e->d_ill_list.p;
+    r.finish_count = e->d_ill_count.p;
+    r.team_w = 0;
+    r.handoff = nullptr;
+    r.queue = a.queue + 3;
+    HIPCHK(lk_launch_solve(r, e->cfg.fitting_model, e->cfg.interpolation, 16, e->stream));
+  }
+  return LK_ERROR_NONE;
+}
+
 static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
   if (e->timing)
     HIPCHK(hipEventRecord(e->ev_s0, e->stream));
@@ -1170,7 +1205,11 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
       if (rc)
         return rc;
     }
-    HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, kGroupOfClass[c], e->stream));
+    {
+      int rc = launch_groups(e, a, kGroupOfClass[c]);
+      if (rc)
+        return rc;
+    }
   }
   if (e->timing) {
     HIPCHK(hipEventRecord(e->ev_s1, e->stream));
@@ -1250,7 +1289,11 @@ int lk_correlate(lk_engine *e, int sector, float *guess_inout, lk_result *out) {
     if (rc)
       return rc;
   }
-  HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, group, e->stream));
+  {
+    int rc = launch_groups(e, a, group);
+    if (rc)
+      return rc;
+  }
   if (e->timing) {
     HIPCHK(hipEventRecord(e->ev_s1, e->stream));
     e->solve_timed = true;
@@ -1396,6 +1439,7 @@ int lk_get_stats(lk_engine *e, lk_stats *out) {
       s.evaluations += h[4 * (size_t)i];
       s.sample_evaluations += h[4 * (size_t)i + 1];
       s.point_iterations += h[4 * (size_t)i + 2];
+      s.ill_conditioned_solves += h[4 * (size_t)i + 3];
     }
     // 25 B per sample-evaluation + 196 B per evaluation
     s.algorithmic_bytes = 25ull * s.sample_evaluations + 196ull * s.evaluations;

@@ -32,6 +32,14 @@
 #include <float.h>
 #include <stdlib.h>
 
+// Smallest pivot ratio d_j / A_jj the fast flavour factors through (below it the sector goes to
+// the SAFE kernel and the reference's QR).  1e-3 sent 0.4 % of config 4's solves there and, before
+// that pass existed, cost its 1 % tail a factor of ten against the reference; root-free Cholesky
+// in float32 is fine down to 1e-6.
+#ifndef LK_FAST_PIVOT
+#define LK_FAST_PIVOT 1e-6f
+#endif
+
 namespace {
 
 constexpr int kWave = 64;
@@ -1018,7 +1026,7 @@ __device__ __forceinline__ void colpiv_qr_solve_row16(const float (&M)[N * N], c
 
 // S holds the raw sums (upper triangle row-major, b, chi); p += dp.
 template <int P, bool SAFE>
-__device__ __forceinline__ void damped_step(const Sums<P> &S, float lambda, float scaling,
+__device__ __forceinline__ bool damped_step(const Sums<P> &S, float lambda, float scaling,
                                             float (&p)[6], bool starved, float *dp_out = nullptr,
                                             bool row16 = false) {
   // U[i][j], i <= j: starts as the scaled, damped upper triangle of A
@@ -1040,7 +1048,8 @@ __device__ __forceinline__ void damped_step(const Sums<P> &S, float lambda, floa
   }
   // A pivot d_j is what remains of the diagonal entry after eliminating the earlier
   // parameters; d_j / A_jj is scale free.  Healthy speckle gives >= 0.1; a damped singular
-  // system gives ~lambda.  Below 1e-3 the reference's pivoting decides the answer.
+  // system gives ~lambda.  The SAFE flavour switches to the reference's QR below 1e-3; the fast
+  // flavour factors through down to LK_FAST_PIVOT and hands the sector to the SAFE kernel below.
   // A starved level (see evaluate<>) always takes the reference's solver: its sums are
   // bit-identical to the reference's, so the whole trajectory is.
   bool well_conditioned = !starved;
@@ -1055,7 +1064,7 @@ __device__ __forceinline__ void damped_step(const Sums<P> &S, float lambda, floa
       w[k] = U[k][j] * d[k];
       dj = __builtin_fmaf(-U[k][j], w[k], dj);
     }
-    const bool ok = dj > ajj * 1e-3f && dj > dmax * 1e-7f; // false for NaN as well
+    const bool ok = dj > ajj * (SAFE ? 1e-3f : LK_FAST_PIVOT) && dj > dmax * 1e-7f; // false for NaN as well
     well_conditioned = well_conditioned && ok;
     d[j] = (SAFE || ok) ? dj : 0.f;
     // v_rcp_f32 (1 ulp) instead of a correctly rounded division: this factorisation is not
@@ -1114,6 +1123,7 @@ __device__ __forceinline__ void damped_step(const Sums<P> &S, float lambda, floa
     if (dp_out)
       dp_out[i] = x[i];
   }
+  return well_conditioned; // false: a pivot was bad (fast flavour: that parameter's step is zero; SAFE: the QR ran)
 }
 
 // translate_model_parameters (pyramid_class.cpp:260-287)
@@ -1157,6 +1167,7 @@ struct Cold {
   float lambda, lg_chi, c0x, c0y;
   int iteration, reached, error, level, level_old, s, use_saved;
   uint32_t n_evals, n_sample_evals, n_point_iters;
+  uint32_t n_ill; // damped solves that met a bad pivot (well-conditioned speckle: 0)
 };
 constexpr int kColdWords = sizeof(Cold) / 4;
 
@@ -1299,7 +1310,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
   // STARVED kernel, a.eval_cap > 0: a lane that has used up its evaluations parks the sector
   // in the middle of its level for the 16-lane finisher (the 63 other lanes of the wavefront
   // are not kept waiting for one sector that runs into max_iters)
-  auto park = [&](const Cold &k) {
+  auto park = [&](const Cold &k, uint32_t *list, uint32_t *count) {
     uint32_t *m = a.mid_state + (size_t)k.s * kLkMidWords;
     const uint32_t *w = reinterpret_cast<const uint32_t *>(&k);
 #pragma unroll
@@ -1309,7 +1320,10 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
     for (int i = 0; i < 6; ++i)
       m[kColdWords + i] = __float_as_uint(p[i]);
     m[kColdWords + 6] = (uint32_t)phase;
-    a.finish_list[atomicAdd(a.finish_count, 1u)] = (uint32_t)k.s;
+    // one list entry per sector: the first lane of the (possibly widened) group, of team rank 0
+    const int lanes = GROUP == 32 ? (wide ? 64 : 32) : GROUP == 16 ? width : GROUP;
+    if (((int)threadIdx.x & (lanes - 1)) == 0 && team.rank == 0)
+      list[atomicAdd(count, 1u)] = (uint32_t)k.s;
     phase = PH_FETCH;
   };
   int steps = 0; // evaluations of the current sector in this kernel (STARVED: eval_cap)
@@ -1343,7 +1357,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
         a.stats[(size_t)k.s * 4 + 0] = k.n_evals;
         a.stats[(size_t)k.s * 4 + 1] = k.n_sample_evals;
         a.stats[(size_t)k.s * 4 + 2] = k.n_point_iters;
-        a.stats[(size_t)k.s * 4 + 3] = 0;
+        a.stats[(size_t)k.s * 4 + 3] = k.n_ill;
       }
       if (starved) {
         LkHandoff h{};
@@ -1371,6 +1385,8 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
     }
     if (phase == PH_FETCH && may_fetch) { // take the next sector
       int slot = 0;
+      // (lists of parked sectors: their length is read BEFORE the ticket is drawn - see the rewind below)
+      const int n_parked = (finisher || a.resume) ? (int)*(const volatile uint32_t *)a.finish_count : 0;
       if (!a.persistent) { // one sector per group, handed out by position (see launch_solve_g)
         // workgroups are dealt round-robin over the 8 XCDs: give each XCD one contiguous run
         // of sectors (neighbouring sectors share image rows in its L2)
@@ -1391,8 +1407,15 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
         slot = __shfl(slot, ((int)threadIdx.x & 63) & ~(GROUP - 1), 64);
       }
       steps = 0;
-      if (finisher) { // resume a sector the starved-level kernel parked in the middle of a level
-        if (slot < (int)*a.finish_count) {
+      if (finisher || a.resume) { // resume a sector an earlier launch parked in the middle of a level
+        if (a.resume && !finisher && (int)threadIdx.x % GROUP == 0 &&
+            slot == n_parked + (int)gridDim.x * (THREADS / GROUP) - 1) {
+          // every group draws exactly one ticket past the end of the list; whoever draws the last
+          // of those rewinds list and queue for the next solve (no memsets between the launches)
+          *a.finish_count = 0u;
+          *a.queue = 0u;
+        }
+        if (slot < n_parked) {
           Cold k;
           const int s_idx = (int)a.finish_list[slot];
           const uint32_t *m = a.mid_state + (size_t)s_idx * kLkMidWords;
@@ -1582,8 +1605,27 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
 #pragma unroll
         for (int i = 0; i < P; ++i)
           tent[i] = p[i];
-        damped_step<P, SAFE || STARVED>(S, lam_use, c.scaling, p, starved, nullptr, finisher); // p += dp (compute_model_parameters)
-        if (phase == PH_EVAL0) {
+        // (16-lane SAFE kernel: every lane of a row holds the same system - the QR runs spread over the row)
+        const bool wc = damped_step<P, SAFE || STARVED>(S, lam_use, c.scaling, p, starved, nullptr, SAFE && GROUP == 16); // p += dp
+        if (!wc && !starved)
+          ++k.n_ill;
+        bool ill_parked = false;
+        if constexpr (!SAFE && !STARVED) {
+          if (!wc && a.ill_list) {
+            // a bad pivot: the reference's rank-revealing QR decides this step.  Undo it and hand
+            // the sector, as it was before this evaluation, to the SAFE kernel.
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+              p[i] = tent[i];
+            --k.n_evals;
+            k.n_sample_evals -= (uint32_t)c.n;
+            park(k, a.ill_list, a.ill_count);
+            ill_parked = true;
+          }
+        }
+        if (ill_parked) {
+          // nothing else happens to this sector in this launch
+        } else if (phase == PH_EVAL0) {
           ++k.n_point_iters;
           k.lg_chi = chi;
           k.use_saved = 1;
@@ -1649,7 +1691,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
       else if (handed)
         hand_over(k);
       else if (STARVED && a.eval_cap > 0 && ++steps >= a.eval_cap)
-        park(k);
+        park(k, a.finish_list, a.finish_count);
       else
         cold.store(cold_slot, k);
     }
@@ -2030,6 +2072,16 @@ static hipError_t launch_solve_gs(const LkSolveArgs &a, hipStream_t st) {
   b.persistent = force_persistent >= 0 ? force_persistent : (want > 2 * resident ? 1 : 0);
   if (GROUP == 1)
     b.persistent = 0; // every lane takes exactly one sector
+  if (GROUP == 16 && SAFE && a.resume && !a.finisher) {
+    // sectors parked with a bad pivot: normally none - a small grid that retires at once and
+    // rewinds its own list and queue (they start at zero: lk_commit_sectors)
+    b.persistent = 1;
+    b.chunk = 0;
+    const int grid = want < 128 ? want : 128;
+    hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, GROUP, THREADS, SAFE>), dim3((unsigned)grid), dim3(THREADS), 0,
+                       st, b);
+    return hipGetLastError();
+  }
   if (GROUP == 16 && SAFE && a.finisher) {
     // the finisher pulls parked sectors from finish_list until *finish_count (known only on
     // the device) is used up: as many wavefronts as could be needed, capped by what is resident

@@ -91,6 +91,7 @@ typedef struct {
   uint64_t sample_evaluations;/* sum over evaluations of the sector's n_L */
   uint64_t point_iterations;  /* per sector and level: LM trips + 1 (evaluation #0) */
   uint64_t algorithmic_bytes; /* 25*sample_evaluations + 196*evaluations */
+  uint64_t ill_conditioned_solves; /* damped solves (outside starved levels) that met a bad pivot */
   float solve_ms;             /* HIP-event time of the solve kernel(s) of the last call */
   float pyramid_ms;           /* HIP-event time of the last pyramid build */
 } lk_stats;

@@ -35,4 +35,4 @@ st = e.stats()
 ms = np.array(ms)
 print(f"{wl.name}\n solve_ms min {ms.min():.4f} median {np.median(ms):.4f}  pit/s {st['point_iterations'] / (np.median(ms) * 1e-3):.3e}"
       f"  alg GB/s {st['algorithmic_bytes'] / (np.median(ms) * 1e-3) / 1e9:.1f}  frac {st['algorithmic_bytes'] / (np.median(ms) * 1e-3) / 8e12:.4f}"
-      f"  evals/sector {st['evaluations'] / st['sectors']:.2f}  errfree {(r['error_code'] == 0).mean():.4f}")
+      f"  evals/sector {st['evaluations'] / st['sectors']:.2f}  ill {st['ill_conditioned_solves']}  errfree {(r['error_code'] == 0).mean():.4f}")
