@@ -317,7 +317,8 @@ def main():
                        "step": "pyramid(und)+pyramid(def)+solve, inputs resident in HBM"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("lk_solve_kernel<fm_UVUxUyVxVy, im_bicubic> (32-lane groups, 2 sectors per wavefront)"
+                         "kernel": ("lk_solve_kernel<fm_UVUxUyVxVy, im_bicubic> (32-lane groups, 2 sectors per wavefront; the events "
+                                    "also bracket the SAFE pass for ill-conditioned sectors, an empty 4 us launch here)"
                                     if not strong else
                                     "lk_solve_kernel<fm_UVUxUyVxVy, im_bicubic>: all launches of one solve "
                                     "(one-lane starved-level kernel, finisher, 16-lane groups)"),
