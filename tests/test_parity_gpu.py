@@ -1132,8 +1132,11 @@ def test_row_distributed_qr_is_bit_identical(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [1, 2, 3])
-def test_random_mix_of_sectors(oracle, seed):
+@pytest.mark.parametrize("seed,model,interp", [(1, ca.FM_UVUXUYVXVY, ca.IM_BICUBIC), (2, ca.FM_UVUXUYVXVY, ca.IM_BICUBIC),
+                                               (3, ca.FM_UVUXUYVXVY, ca.IM_BICUBIC), (4, ca.FM_UVQ, ca.IM_BILINEAR),
+                                               (5, ca.FM_UV, ca.IM_NEAREST), (6, ca.FM_U, ca.IM_BICUBIC),
+                                               (7, ca.FM_UVUXUYVXVY, ca.IM_BILINEAR)])
+def test_random_mix_of_sectors(oracle, seed, model, interp):
     """Sixty sectors of every size class at once - 7x7 ... 301x301 rectangles, decimated explicit
     lists - on a 4-level pyramid, so that one engine runs the one-lane kernel, the finisher, 16-
     and 32-lane groups with alignment / adaptive width / solo, workgroup groups and teams in
@@ -1154,7 +1157,7 @@ def test_random_mix_of_sectors(oracle, seed):
         specs.append((explicit, cx - half, cy - half, cx + half, cy + half))
 
     def engine(invariant):
-        e = ca.HipCorrelationEngine(fitting_model=ca.FM_UVUXUYVXVY, py_stop=3)
+        e = ca.HipCorrelationEngine(fitting_model=model, interpolation=interp, py_stop=3)
         e.set_batch_invariant(invariant)
         e.set_undeformed_image(und)
         e.set_deformed_image(dfm)
@@ -1168,7 +1171,7 @@ def test_random_mix_of_sectors(oracle, seed):
 
     os_ = []
     for T, solver in ((1, 0), (8, 0), (1, 2)):
-        o = oracle.Oracle(n_threads=T, solver=solver, py_stop=3)
+        o = oracle.Oracle(n_threads=T, solver=solver, py_stop=3, model=model, interp=interp)
         o.set_image(0, und)
         o.set_image(1, dfm)
         os_.append(o)
