@@ -698,6 +698,8 @@ def _report_table(text):
     (1, 0, 1, ca.FM_UVUXUYVXVY),    # annular, strict Lagrangian
     (2, 2, 0, ca.FM_UVUXUYVXVY),    # blob, Eulerian
     (2, 1, 1, ca.FM_UVUXUYVXVY),    # blob, Lagrangian
+    (3, 1, 1, ca.FM_UVUXUYVXVY),    # rectangular, Lagrangian, a finer grid (11 x 9 sectors of 15 x 17 samples)
+    (3, 2, 0, ca.FM_UVQ),           # the same grid, Eulerian, rigid + rotation
 ])
 def test_sequence_tracking_against_manager_oracle(oracle, domain, deformation, reference, model):
     """perform_multiframe_correlation on the HIP engine: frame roles (und <- def <- nxt with the
@@ -705,6 +707,8 @@ def test_sequence_tracking_against_manager_oracle(oracle, domain, deformation, r
     report, compared with the CPU restatement of managerClass driving the CPU oracle."""
     from correlation_amd import tracker as tk
     from oracle import lk_manager_oracle as mo
+    fine = domain == 3
+    domain = 0 if fine else domain
     frames = ca.speckle.speckle_sequence(256, 256, 5, velocity=(0.9, -0.5), dilation=4e-4, seed=3)
     names = [f"f{i}.pgm" for i in range(len(frames))]
     guess = [0.5, -0.25, 0.0, 0.0, 0.0, 0.0]
@@ -715,7 +719,7 @@ def test_sequence_tracking_against_manager_oracle(oracle, domain, deformation, r
     o.set_image(1, frames[1])
     m = mo.ManagerOracle(o, model, domain, deformation, reference, mo.ERRMODE_CONTINUE, guess)
     if domain == 0:
-        args = (40.0, 44.0, 215.0, 211.0, 127.5, 127.5, 4, 3)
+        args = (40.0, 44.0, 215.0, 211.0, 127.5, 127.5, 11 if fine else 4, 9 if fine else 3)
         t.set_rect_domain(*args), m.set_rect_domain(*args)
     elif domain == 1:
         args = (30.0, 78.0, 128.0, 126.0, 2, 3)
