@@ -72,6 +72,18 @@ struct LkSolveArgs {
   int max_iters;
 };
 
+struct LkRewarpArgs { // level-0 sample lists moved by the last level-0 evaluation's parameters
+  const float2 *src_xy;    // lists before (explicit sectors)
+  const uint32_t *src_off; // [S+1]
+  const int4 *src_rect;    // [S] implicit rectangles before (width 0: explicit)
+  const uint32_t *dst_off; // [S+1] prefix of the level-0 counts: every sector explicit afterwards
+  float2 *dst_xy;
+  const float2 *center;    // [S] centres of the last solve
+  const float *p;          // [S][6]
+  int n_sectors;
+  uint32_t total;          // dst_off[S]
+};
+
 struct LkEvalArgs { // stand-alone evaluation (known-answer tests)
   const LkLevelView *lv;
   const float2 *center;

@@ -37,6 +37,12 @@ hipError_t lk_launch_guess(const float2 *center, const float *last_p, float *pre
                            int frame, int constant_velocity, hipStream_t st);
 hipError_t lk_launch_warp_points(const float2 *xy, int n, float cx, float cy, int model, const float *d_p,
                                  float2 *out, hipStream_t st);
+hipError_t lk_launch_rewarp(const LkRewarpArgs &a, int model, hipStream_t st);
+int lk_decimate_tiles(uint32_t n_max);
+hipError_t lk_launch_decimate(const float2 *xy_prev, const uint32_t *off_prev, const uint32_t *n_prev, uint32_t n_max,
+                              int level_delta, int n_sectors, uint32_t *pos, uint32_t *tiles, float2 *xy_out,
+                              uint32_t *off_out, uint32_t *n_out, hipStream_t st);
+hipError_t lk_launch_mean_center(const float2 *xy, const uint32_t *off, int n_sectors, float2 *center, hipStream_t st);
 
 namespace {
 
@@ -140,6 +146,12 @@ struct lk_engine {
   std::vector<HostSector> hs_backup; // the lists before the last lk_translate / lk_rewarp_sectors
   bool committed = false;
   bool recommit_pending = false; // lk_update_sector moved sample lists: rebuild before the next solve
+  // lk_rewarp_sectors rebuilds the lists on the device: hs[].xy / cx / cy are stale until a host
+  // consumer asks for them (materialize_host); the previous level-0 lists stay in d_xy0_alt
+  bool lists_on_device = false, backup_on_device = false;
+  DevBuf<float2> d_xy0_alt;
+  DevBuf<uint32_t> d_off0_alt, d_pos, d_tiles, d_level_total;
+  std::vector<float> h_center_prev;
   int S = 0;
   std::vector<uint32_t> h_off[LK_MAX_LEVELS];
   DevBuf<float2> d_xy[LK_MAX_LEVELS];
@@ -245,6 +257,11 @@ void lk_destroy(lk_engine *e) {
     e->d_rect[l].release();
   }
   e->d_center.release();
+  e->d_xy0_alt.release();
+  e->d_off0_alt.release();
+  e->d_pos.release();
+  e->d_tiles.release();
+  e->d_level_total.release();
   e->d_guess.release();
   e->d_last_p.release();
   e->d_last_eval_p.release();
@@ -511,9 +528,39 @@ int lk_get_pyramid_level(lk_engine *e, int slot, int level, uint8_t *host_out, i
 // ------------------------------------------------------------------------------------
 // sectors
 // ------------------------------------------------------------------------------------
+// Level-0 lists that live on the device only (after lk_rewarp_sectors) -> HostSector records.
+static int lists_from_device(lk_engine *e, const float2 *d_xy0, const std::vector<float> &centers,
+                             std::vector<HostSector> &out) {
+  const size_t S = (size_t)e->S, total = e->h_off[0][S];
+  std::vector<float> xy(2 * total + 2);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipMemcpyAsync(xy.data(), d_xy0, total * sizeof(float2), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (size_t s = 0; s < S; ++s) {
+    HostSector &h = out[s];
+    h.xy.assign(xy.begin() + 2 * (size_t)e->h_off[0][s], xy.begin() + 2 * (size_t)e->h_off[0][s + 1]);
+    h.is_rect = false;
+    h.cx = centers[2 * s];
+    h.cy = centers[2 * s + 1];
+  }
+  return LK_ERROR_NONE;
+}
+
+// every entry point that reads or edits e->hs calls this first
+static int materialize_host(lk_engine *e) {
+  if (!e->lists_on_device)
+    return LK_ERROR_NONE;
+  int rc = lists_from_device(e, e->d_xy[0].p, e->h_center, e->hs);
+  if (rc)
+    return rc;
+  e->lists_on_device = false;
+  return LK_ERROR_NONE;
+}
+
 int lk_clear_sectors(lk_engine *e) {
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
+  e->lists_on_device = e->backup_on_device = false;
   e->hs.clear();
   e->committed = false;
   e->S = 0;
@@ -521,7 +568,7 @@ int lk_clear_sectors(lk_engine *e) {
 }
 
 static HostSector *sector_slot(lk_engine *e, int sector) {
-  if (sector < 0)
+  if (sector < 0 || materialize_host(e))
     return nullptr;
   if ((size_t)sector >= e->hs.size())
     e->hs.resize((size_t)sector + 1);
@@ -562,6 +609,7 @@ int lk_set_rect_grid(lk_engine *e, float x_begin, float y_begin, float x_end, fl
   lkroi::RectGrid g = lkroi::rect_grid(x_begin, y_begin, x_end, y_end, hs, vs);
   if (g.xdim < 0 || g.ydim < 0)
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_rect_grid: domain smaller than the grid");
+  e->lists_on_device = e->backup_on_device = false;
   e->hs.clear();
   e->hs.resize((size_t)count);
   e->committed = false;
@@ -637,9 +685,35 @@ int lk_set_sector_points(lk_engine *e, int sector, const float *xy, int n, int u
   return LK_ERROR_NONE;
 }
 
+// Starved levels (at most 2P samples for P parameters; always the coarsest ones) are solved
+// first by the one-lane-per-sector kernel, bit-identically to the reference.  Needs h_class,
+// h_rect and h_off of the coarsest level.
+static int refresh_starved(lk_engine *e) {
+  const int S = (int)e->h_class.size();
+  for (int c = 0; c < kNumClasses; ++c)
+    e->class_starved[c] = false;
+  if (const char *f = std::getenv("LK_FORCE_SAFE")) // tuning / test hook
+    e->force_safe = std::atoi(f) != 0;
+  const int l = e->cfg.py_stop; // counts only shrink with the level: test the coarsest
+  bool any_starved = false;
+  for (int s = 0; s < S; ++s) {
+    const int4 r = e->h_rect[l][(size_t)s];
+    const int n = r.z > 0 ? r.w : (int)(e->h_off[l][(size_t)s + 1] - e->h_off[l][(size_t)s]);
+    if (n <= 2 * e->P)
+      e->class_starved[e->h_class[(size_t)s]] = any_starved = true;
+  }
+  if (any_starved) {
+    HIPCHK(e->d_finish_list.ensure((size_t)S));
+    HIPCHK(e->d_finish_count.ensure(1));
+  }
+  return LK_ERROR_NONE;
+}
+
 // keep_state: a re-commit after the sample lists moved (Lagrangian descriptions) keeps the
 // sequence state of the sectors (guess history, last results)
 static int commit_impl(lk_engine *e, bool keep_state) {
+  if (int rc = materialize_host(e)) // (a no-op after any edit: editors fetch the lists first)
+    return rc;
   const int S = (int)e->hs.size();
   if (S == 0)
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_commit_sectors: no sectors");
@@ -800,20 +874,10 @@ static int commit_impl(lk_engine *e, bool keep_state) {
         e->h_order.push_back((uint32_t)s);
   }
   e->class_begin[kNumClasses] = (int)e->h_order.size();
-  // Starved levels (at most 2P samples for P parameters; always the coarsest ones) are
-  // solved first by the one-lane-per-sector kernel, bit-identically to the reference.
-  for (int c = 0; c < kNumClasses; ++c)
-    e->class_starved[c] = false;
-  if (const char *f = std::getenv("LK_FORCE_SAFE")) // tuning / test hook
-    e->force_safe = std::atoi(f) != 0;
   {
-    const int l = cfg.py_stop; // counts only shrink with the level: test the coarsest
-    for (int s = 0; s < S; ++s) {
-      const int4 r = e->h_rect[l][(size_t)s];
-      const int n = r.z > 0 ? r.w : (int)(e->h_off[l][(size_t)s + 1] - e->h_off[l][(size_t)s]);
-      if (n <= 2 * e->P)
-        e->class_starved[e->h_class[(size_t)s]] = true;
-    }
+    int rc = refresh_starved(e);
+    if (rc)
+      return rc;
   }
   HIPCHK(e->d_order.ensure((size_t)S));
   HIPCHK(hipMemcpy(e->d_order.p, e->h_order.data(), (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -821,17 +885,10 @@ static int commit_impl(lk_engine *e, bool keep_state) {
   HIPCHK(e->d_queue.ensure(8 * kNumClasses));
   HIPCHK(hipMemset(e->d_queue.p, 0, 8 * kNumClasses * sizeof(uint32_t))); // (the SAFE pass rewinds its own queue)
   HIPCHK(e->d_handoff.ensure((size_t)S));
-  bool any_starved = false;
-  for (int c = 0; c < kNumClasses; ++c)
-    any_starved = any_starved || e->class_starved[c];
   HIPCHK(e->d_mid.ensure((size_t)S * kLkMidWords));
   HIPCHK(e->d_ill_list.ensure((size_t)S));
   HIPCHK(e->d_ill_count.ensure(1));
   HIPCHK(hipMemset(e->d_ill_count.p, 0, sizeof(uint32_t)));
-  if (any_starved) {
-    HIPCHK(e->d_finish_list.ensure((size_t)S));
-    HIPCHK(e->d_finish_count.ensure(1));
-  }
   if (const char *f = std::getenv("LK_EVAL_CAP")) // tuning / test hook
     e->eval_cap = std::atoi(f);
   HIPCHK(e->d_scratch.ensure(64));
@@ -845,7 +902,8 @@ static int commit_impl(lk_engine *e, bool keep_state) {
 int lk_commit_sectors(lk_engine *e) {
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
-  return commit_impl(e, false);
+  int rc = materialize_host(e);
+  return rc ? rc : commit_impl(e, false);
 }
 
 // Lagrangian description, CPU-engine semantics (manager_class.cpp:381-419): every sample of
@@ -910,7 +968,13 @@ int lk_translate_sectors(lk_engine *e, const float *offsets_xy, const float *cen
     return LK_ERROR_BAD_DOMAIN;
   if (!e->committed || !offsets_xy)
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_translate_sectors: sectors are not committed");
+  {
+    int rc = materialize_host(e);
+    if (rc)
+      return rc;
+  }
   e->hs_backup = e->hs;
+  e->backup_on_device = false;
   for (int s = 0; s < e->S; ++s)
     translate_one(e->hs[(size_t)s], offsets_xy[2 * (size_t)s], offsets_xy[2 * (size_t)s + 1],
                   centers_xy ? centers_xy + 2 * (size_t)s : nullptr);
@@ -921,16 +985,114 @@ int lk_translate_sectors(lk_engine *e, const float *offsets_xy, const float *cen
 // last solve - CorrelationClass::getDefXY0, i.e. the samples warped with the parameters of
 // the LAST level-0 evaluation about the solve's centre (correlation_class.cpp:884-896) -
 // become the undeformed samples of the next frame.
+//
+// Device path (default): the lists never leave the GPU.  One kernel warps every level-0 sample
+// (implicit rectangles become explicit lists), one order-preserving compaction per coarser level
+// applies the decimation rule to all sectors at once, a one-lane-per-sector kernel recomputes the
+// mean centres where the caller gives none; the host reads back only the per-level offsets
+// (starved-level bookkeeping).  LK_HOST_REWARP=1 keeps the host path (tests compare the two).
+static int rewarp_on_device(lk_engine *e, const float *centers_xy) {
+  const int S = e->S;
+  const lk_config &cfg = e->cfg;
+  hipStream_t st = e->stream;
+  const int first = cfg.py_start == 0 ? cfg.py_step : cfg.py_start; // pyramid_class.cpp:299
+  std::vector<int> levels{0};
+  for (int l = first; l <= cfg.py_stop; l += cfg.py_step)
+    levels.push_back(l);
+  std::vector<uint32_t> off0((size_t)S + 1, 0u);
+  bool explicit_already = true;
+  uint64_t sum = 0;
+  for (int s = 0; s < S; ++s) {
+    const int4 r = e->h_rect[0][(size_t)s];
+    sum += r.z > 0 ? (uint32_t)r.w : e->h_off[0][(size_t)s + 1] - e->h_off[0][(size_t)s];
+    explicit_already = explicit_already && r.z == 0;
+    off0[(size_t)s + 1] = (uint32_t)sum;
+  }
+  if (sum >= 0xffffffffull)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_rewarp_sectors: more than 2^32 samples");
+  const uint32_t total = (uint32_t)sum;
+  HIPCHK(e->d_xy0_alt.ensure((size_t)total + 1));
+  const uint32_t *dst_off = e->d_off[0].p;
+  if (!explicit_already) { // (a blocking copy: the alternate table has no reader in flight)
+    HIPCHK(e->d_off0_alt.ensure((size_t)S + 1));
+    HIPCHK(hipMemcpy(e->d_off0_alt.p, off0.data(), ((size_t)S + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    dst_off = e->d_off0_alt.p;
+  }
+  LkRewarpArgs a{};
+  a.src_xy = e->d_xy[0].p;
+  a.src_off = e->d_off[0].p;
+  a.src_rect = e->d_rect[0].p;
+  a.dst_off = dst_off;
+  a.dst_xy = e->d_xy0_alt.p;
+  a.center = e->d_center.p;
+  a.p = e->d_last_eval_p.p;
+  a.n_sectors = S;
+  a.total = total;
+  HIPCHK(lk_launch_rewarp(a, cfg.fitting_model, st));
+  // what lk_restore_sectors needs: the previous lists stay in the alternate buffer when they
+  // were device-built too, otherwise the host records are still good
+  if (e->lists_on_device) {
+    e->backup_on_device = true;
+  } else {
+    e->hs_backup = e->hs;
+    e->backup_on_device = false;
+  }
+  e->h_center_prev = e->h_center;
+  std::swap(e->d_xy[0], e->d_xy0_alt);
+  if (!explicit_already)
+    std::swap(e->d_off[0], e->d_off0_alt);
+  e->h_off[0] = off0;
+  for (int l : levels) {
+    HIPCHK(hipMemsetAsync(e->d_rect[l].p, 0, (size_t)S * sizeof(int4), st));
+    e->h_rect[l].assign((size_t)S, make_int4(0, 0, 0, 0));
+  }
+  HIPCHK(e->d_level_total.ensure(LK_MAX_LEVELS));
+  HIPCHK(hipMemsetD32Async((hipDeviceptr_t)e->d_level_total.p, (int)total, 1, st));
+  HIPCHK(e->d_pos.ensure((size_t)total + 1));
+  HIPCHK(e->d_tiles.ensure((size_t)lk_decimate_tiles(total) + 2));
+  for (size_t li = 1; li < levels.size(); ++li) {
+    const int l = levels[li], pl = levels[li - 1];
+    HIPCHK(e->d_xy[l].ensure((size_t)total + 1)); // any count up to the finer level's can be kept
+    HIPCHK(lk_launch_decimate(e->d_xy[pl].p, e->d_off[pl].p, e->d_level_total.p + pl, total, l - pl, S, e->d_pos.p,
+                              e->d_tiles.p, e->d_xy[l].p, e->d_off[l].p, e->d_level_total.p + l, st));
+    e->h_off[l].resize((size_t)S + 1);
+    HIPCHK(hipMemcpyAsync(e->h_off[l].data(), e->d_off[l].p, ((size_t)S + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                          st));
+  }
+  if (centers_xy) {
+    e->h_center.assign(centers_xy, centers_xy + 2 * (size_t)S);
+    HIPCHK(hipMemcpyAsync(e->d_center.p, e->h_center.data(), 2 * (size_t)S * sizeof(float), hipMemcpyHostToDevice, st));
+  } else {
+    HIPCHK(lk_launch_mean_center(e->d_xy[0].p, e->d_off[0].p, S, e->d_center.p, st));
+    HIPCHK(hipMemcpyAsync(e->h_center.data(), e->d_center.p, 2 * (size_t)S * sizeof(float), hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  e->lists_on_device = true;
+  e->lv_dirty = true;
+  e->stats_valid = false;
+  return refresh_starved(e);
+}
+
 int lk_rewarp_sectors(lk_engine *e, const float *centers_xy) {
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
   if (!e->committed)
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_rewarp_sectors: sectors are not committed");
   HIPCHK(hipSetDevice(e->cfg.device));
+  const char *f = std::getenv("LK_HOST_REWARP"); // test hook, read per call
+  const bool host_path = f && std::atoi(f) != 0;
+  if (!host_path && !e->recommit_pending)
+    return rewarp_on_device(e, centers_xy);
+  {
+    int rc = materialize_host(e);
+    if (rc)
+      return rc;
+  }
   std::vector<float> ev(6 * (size_t)e->S);
   HIPCHK(hipMemcpyAsync(ev.data(), e->d_last_eval_p.p, ev.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   e->hs_backup = e->hs;
+  e->backup_on_device = false;
   for (int s = 0; s < e->S; ++s)
     rewarp_one(e->hs[(size_t)s], e->cfg.fitting_model, &ev[6 * (size_t)s],
                centers_xy ? centers_xy + 2 * (size_t)s : nullptr);
@@ -949,6 +1111,11 @@ int lk_update_sector(lk_engine *e, int sector, int mode) {
   if (mode == 2)
     return LK_ERROR_NONE;
   HIPCHK(hipSetDevice(e->cfg.device));
+  {
+    int rc = materialize_host(e);
+    if (rc)
+      return rc;
+  }
   lk_result r;
   float ev[6];
   HIPCHK(hipMemcpyAsync(&r, e->d_result.p + sector, sizeof(r), hipMemcpyDeviceToHost, e->stream));
@@ -971,7 +1138,19 @@ int lk_update_sector(lk_engine *e, int sector, int mode) {
 int lk_restore_sectors(lk_engine *e, int first_sector) {
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
-  if (!e->committed || first_sector < 0 || e->hs_backup.size() != e->hs.size())
+  if (!e->committed || first_sector < 0)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_restore_sectors: nothing to restore");
+  {
+    int rc = materialize_host(e);
+    if (!rc && e->backup_on_device) {
+      e->hs_backup = e->hs;
+      rc = lists_from_device(e, e->d_xy0_alt.p, e->h_center_prev, e->hs_backup);
+      e->backup_on_device = false;
+    }
+    if (rc)
+      return rc;
+  }
+  if (e->hs_backup.size() != e->hs.size())
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_restore_sectors: nothing to restore");
   for (size_t s = (size_t)first_sector; s < e->hs.size(); ++s)
     e->hs[s] = e->hs_backup[s];
@@ -994,6 +1173,8 @@ int lk_sector_count(const lk_engine *e) { return e ? (e->committed ? e->S : (int
 int lk_get_sector_info(lk_engine *e, int sector, int *n_points, float *cx, float *cy) {
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
+  if (int rc = materialize_host(e))
+    return rc;
   if (sector < 0 || (size_t)sector >= e->hs.size() || !e->hs[(size_t)sector].set)
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_sector_info: unknown sector");
   const HostSector &s = e->hs[(size_t)sector];
@@ -1022,6 +1203,8 @@ int lk_get_sector_level_count(lk_engine *e, int sector, int level, int *n) {
 int lk_get_und_xy(lk_engine *e, int sector, float *xy, int cap, int *count) {
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
+  if (int rc = materialize_host(e))
+    return rc;
   if (sector < 0 || (size_t)sector >= e->hs.size() || !e->hs[(size_t)sector].set)
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_und_xy: unknown sector");
   const HostSector &s = e->hs[(size_t)sector];
@@ -1040,6 +1223,8 @@ int lk_get_def_xy(lk_engine *e, int sector, const float *p, float *xy, int cap, 
     return LK_ERROR_BAD_DOMAIN;
   if (!e->committed || sector < 0 || sector >= e->S || !p)
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_def_xy: unknown sector");
+  if (int rc = materialize_host(e))
+    return rc;
   const std::vector<float> pts = e->hs[(size_t)sector].points();
   const int n = (int)(pts.size() / 2);
   if (count)

@@ -2041,6 +2041,164 @@ __global__ void lk_warp_points_kernel(const float2 *xy, int n, float cx, float c
   out[k] = make_float2(xd, yd);
 }
 
+
+// ---- moved sample lists, rebuilt on the device (strict Lagrangian description) ---------------
+// manager_class.cpp:369-380 makes the deformed positions of the last solve the undeformed samples
+// of the next frame; pyramid_class.cpp:289-323 then decimates them level by level.  Sectors are
+// concatenated in sector order, so ONE order-preserving compaction of the whole level is the
+// per-sector compaction of every sector at once.
+template <int MODEL> __global__ void lk_rewarp_kernel(LkRewarpArgs a) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.total)
+    return;
+  int lo = 0, hi = a.n_sectors; // dst_off[lo] <= i < dst_off[hi]: the last such lo owns sample i
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (a.dst_off[mid] <= i)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  const int s = lo;
+  const uint32_t k = i - a.dst_off[s];
+  const int4 rc = a.src_rect[s];
+  float2 q;
+  if (rc.z > 0) { // x outer, y inner (manager_class.cpp:1607-1611)
+    const int h = rc.w / rc.z, col = (int)k / h;
+    q.x = (float)(rc.x + col);
+    q.y = (float)(rc.y + ((int)k - col * h));
+  } else {
+    q = a.src_xy[a.src_off[s] + k];
+  }
+  float p[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+    p[j] = a.p[(size_t)s * 6 + j];
+  const float2 c = a.center[s];
+  float xd, yd, dx, dy;
+  Warp<MODEL>::apply(q.x, q.y, c.x, c.y, p, xd, yd, dx, dy);
+  a.dst_xy[i] = make_float2(xd, yd);
+}
+
+// (int)(v + 0.5f) as the host code computes it: out-of-range and NaN give INT_MIN (cvttss2si)
+__device__ __forceinline__ int round_like_host(float v) {
+  const float t = v + 0.5f;
+  return fabsf(t) < 2147483648.f ? (int)t : (int)0x80000000;
+}
+__device__ __forceinline__ bool decimate_keeps(float2 q, int mag) {
+  return round_like_host(q.x) % mag == 0 && round_like_host(q.y) % mag == 0;
+}
+
+constexpr int kScanThreads = 256, kScanItems = 4, kScanTile = kScanThreads * kScanItems;
+
+// exclusive sum over the workgroup; *total receives the sum of all
+__device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t v, uint32_t *lds, uint32_t &total) {
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const uint32_t up = __shfl_up(inc, d, kWave);
+    if ((int)(threadIdx.x & (kWave - 1)) >= d)
+      inc += up;
+  }
+  const int wave = (int)threadIdx.x / kWave, n_waves = (int)blockDim.x / kWave;
+  if ((threadIdx.x & (kWave - 1)) == kWave - 1)
+    lds[wave] = inc;
+  __syncthreads();
+  uint32_t before = 0, all = 0;
+  for (int w = 0; w < n_waves; ++w) {
+    const uint32_t t = lds[w];
+    before += w < wave ? t : 0u;
+    all += t;
+  }
+  __syncthreads();
+  total = all;
+  return before + inc - v;
+}
+
+// pass 1: keep flag (bit 31) and position among the kept samples of the own 1024-sample tile
+__global__ void __launch_bounds__(kScanThreads) lk_decimate_flag_kernel(const float2 *xy, const uint32_t *n_ptr, int mag,
+                                                                        uint32_t *pos, uint32_t *tile_count) {
+  __shared__ uint32_t lds[kScanThreads / kWave];
+  const uint32_t n = *n_ptr, base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  bool keep[kScanItems];
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    keep[j] = base + j < n && decimate_keeps(xy[base + j], mag);
+    cnt += keep[j];
+  }
+  uint32_t total;
+  uint32_t at = block_exclusive_sum(cnt, lds, total);
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j)
+    if (base + j < n) {
+      pos[base + j] = at | (keep[j] ? 0x80000000u : 0u);
+      at += keep[j];
+    }
+  if (threadIdx.x == 0)
+    tile_count[blockIdx.x] = total;
+}
+
+// pass 2 (one workgroup): tile counts -> exclusive prefix; [n_tiles] and *n_out get the total
+__global__ void __launch_bounds__(1024) lk_scan_tiles_kernel(uint32_t *tile_count, int n_tiles, uint32_t *n_out) {
+  __shared__ uint32_t lds[1024 / kWave];
+  uint32_t carry = 0;
+  for (int base = 0; base < n_tiles; base += 1024) {
+    const int i = base + (int)threadIdx.x;
+    const uint32_t v = i < n_tiles ? tile_count[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_sum(v, lds, total);
+    if (i < n_tiles)
+      tile_count[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) {
+    tile_count[n_tiles] = carry;
+    *n_out = carry;
+  }
+}
+
+// pass 3: kept samples move to their place, in the coordinates of the coarser level
+__global__ void __launch_bounds__(kScanThreads) lk_decimate_scatter_kernel(const float2 *xy, const uint32_t *n_ptr, float inv,
+                                                                           const uint32_t *pos, const uint32_t *tile_first,
+                                                                           float2 *out) {
+  const uint32_t n = *n_ptr, i = blockIdx.x * kScanThreads + threadIdx.x;
+  if (i >= n)
+    return;
+  const uint32_t w = pos[i];
+  if (w & 0x80000000u) {
+    const float2 q = xy[i];
+    out[tile_first[i / kScanTile] + (w & 0x7fffffffu)] = make_float2(q.x * inv, q.y * inv);
+  }
+}
+
+// pass 4: where every sector's list starts after the compaction
+__global__ void lk_decimate_offsets_kernel(const uint32_t *off_prev, const uint32_t *n_ptr, const uint32_t *pos,
+                                           const uint32_t *tile_first, int n_tiles, int n_sectors, uint32_t *off_new) {
+  const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (s > n_sectors)
+    return;
+  const uint32_t n = *n_ptr, o = off_prev[s];
+  off_new[s] = o < n ? tile_first[o / kScanTile] + (pos[o] & 0x7fffffffu) : tile_first[n_tiles];
+}
+
+// Newton_Raphson(p, n, xy) solves about the float mean of the samples, summed in list order
+// (pyramid_class.cpp:325-340): one lane per sector, sequential
+__global__ void lk_mean_center_kernel(const float2 *xy, const uint32_t *off, int n_sectors, float2 *center) {
+  const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (s >= n_sectors)
+    return;
+  const uint32_t b = off[s], e = off[s + 1];
+  float sx = 0.f, sy = 0.f;
+  for (uint32_t i = b; i < e; ++i) {
+    const float2 q = xy[i];
+    sx += q.x;
+    sy += q.y;
+  }
+  const float n = (float)(e - b);
+  center[s] = make_float2(__fdiv_rn(sx, n), __fdiv_rn(sy, n));
+}
+
 } // namespace
 
 // ------------------------------------------------------------------------------------
@@ -2282,5 +2440,47 @@ hipError_t lk_launch_warp_points(const float2 *xy, int n, float cx, float cy, in
     return hipSuccess;
   hipLaunchKernelGGL(lk_warp_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xy, n, cx,
                      cy, model, d_p, out);
+  return hipGetLastError();
+}
+
+hipError_t lk_launch_rewarp(const LkRewarpArgs &a, int model, hipStream_t st) {
+  if (a.total == 0)
+    return hipSuccess;
+  const dim3 grid((a.total + 255) / 256), block(256);
+  switch (model) {
+  case LK_FM_U: hipLaunchKernelGGL(lk_rewarp_kernel<LK_FM_U>, grid, block, 0, st, a); break;
+  case LK_FM_UV: hipLaunchKernelGGL(lk_rewarp_kernel<LK_FM_UV>, grid, block, 0, st, a); break;
+  case LK_FM_UVQ: hipLaunchKernelGGL(lk_rewarp_kernel<LK_FM_UVQ>, grid, block, 0, st, a); break;
+  default: hipLaunchKernelGGL(lk_rewarp_kernel<LK_FM_UVUXUYVXVY>, grid, block, 0, st, a); break;
+  }
+  return hipGetLastError();
+}
+
+int lk_decimate_tiles(uint32_t n_max) { return (int)((n_max + kScanTile - 1) / kScanTile); }
+
+// One level of pyramid_class.cpp:289-323 for all sectors: xy_prev[*n_prev] (at most n_max) ->
+// xy_out, off_prev[S+1] -> off_out[S+1], *n_out = samples kept.  pos: n_max words,
+// tiles: lk_decimate_tiles(n_max) + 1 words.
+hipError_t lk_launch_decimate(const float2 *xy_prev, const uint32_t *off_prev, const uint32_t *n_prev, uint32_t n_max,
+                              int level_delta, int n_sectors, uint32_t *pos, uint32_t *tiles, float2 *xy_out,
+                              uint32_t *off_out, uint32_t *n_out, hipStream_t st) {
+  const int mag = 1 << level_delta, n_tiles = lk_decimate_tiles(n_max);
+  if (n_tiles == 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(lk_decimate_flag_kernel, dim3((unsigned)n_tiles), dim3(kScanThreads), 0, st, xy_prev, n_prev, mag,
+                     pos, tiles);
+  hipLaunchKernelGGL(lk_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, tiles, n_tiles, n_out);
+  hipLaunchKernelGGL(lk_decimate_scatter_kernel, dim3((n_max + kScanThreads - 1) / kScanThreads), dim3(kScanThreads), 0,
+                     st, xy_prev, n_prev, 1.f / (float)mag, pos, tiles, xy_out);
+  hipLaunchKernelGGL(lk_decimate_offsets_kernel, dim3((unsigned)(n_sectors + 256) / 256), dim3(256), 0, st, off_prev,
+                     n_prev, pos, tiles, n_tiles, n_sectors, off_out);
+  return hipGetLastError();
+}
+
+hipError_t lk_launch_mean_center(const float2 *xy, const uint32_t *off, int n_sectors, float2 *center, hipStream_t st) {
+  if (n_sectors <= 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(lk_mean_center_kernel, dim3((unsigned)(n_sectors + 63) / 64), dim3(64), 0, st, xy, off, n_sectors,
+                     center);
   return hipGetLastError();
 }

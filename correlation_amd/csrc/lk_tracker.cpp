@@ -6,6 +6,7 @@
 // reference's does (manager_class.cpp:2430-2471).
 #include "../../include/lk_tracker.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +15,7 @@
 #include <future>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "lk_roi.hpp"
@@ -36,7 +38,8 @@ struct lk_tracker {
   std::vector<float> contour;
   int results_i = 0, results_j = 0;
   std::vector<lk_frame_result> res, before; // frame_results[]; state before begin_frame
-  std::string report; // the CSV text so far
+  std::string report;                 // the CSV header
+  std::vector<std::string> report_blocks; // + the rows, one block per formatting thread and frame
   bool report_enabled = true;
   std::string err;
   bool begun = false;
@@ -68,6 +71,7 @@ static void put(std::string &r, int v) {
 static void initialize_report(lk_tracker *t) { // manager_class.cpp:2473-2525
   std::string &r = t->report;
   r.clear();
+  t->report_blocks.clear();
   for (const char *name : {"Frame#", "und_file_string", "def_file_string", "und_global_center_x",
                            "und_global_center_y", "und_center_x", "und_center_y", "def_global_center_x",
                            "def_global_center_y", "def_center_x", "def_center_y"}) {
@@ -88,11 +92,11 @@ static void initialize_report(lk_tracker *t) { // manager_class.cpp:2473-2525
   r += "error_code\n";
 }
 
-static void add_frame_to_report(lk_tracker *t, int frame, const char *und, const char *def) { // :2430-2471
-  if (!t->report_enabled)
-    return;
-  std::string &r = t->report;
-  for (const lk_frame_result &s : t->res) {
+// one report row per sector of [first, last), appended to r
+static void report_rows(const lk_tracker *t, size_t first, size_t last, int frame, const char *und, const char *def,
+                        std::string &r) {
+  for (size_t i = first; i < last; ++i) {
+    const lk_frame_result &s = t->res[i];
     put(r, frame);
     r += ',';
     r += und;
@@ -126,6 +130,33 @@ static void add_frame_to_report(lk_tracker *t, int frame, const char *und, const
     put(r, s.error_code);
     r += '\n';
   }
+}
+
+// manager_class.cpp:2430-2471.  ~35 number conversions per sector: on grids of tens of
+// thousands of sectors the rows are formatted by a few threads, each on its own block of
+// sectors, and joined in sector order (the text is the same as the sequential loop's).
+static void add_frame_to_report(lk_tracker *t, int frame, const char *und, const char *def) {
+  if (!t->report_enabled)
+    return;
+  const size_t S = t->res.size();
+  const size_t kRowsPerThread = 2048;
+  size_t workers = std::min<size_t>(S / kRowsPerThread, std::min<size_t>(16, std::thread::hardware_concurrency()));
+  if (workers < 2)
+    workers = 1;
+  const size_t base = t->report_blocks.size();
+  t->report_blocks.resize(base + workers); // blocks are joined only when the text is asked for
+  std::string *part = &t->report_blocks[base];
+  auto work = [=](size_t w) {
+    const size_t first = S * w / workers, last = S * (w + 1) / workers;
+    part[w].reserve((last - first) * (size_t)(96 + 26 * t->P) + 64);
+    report_rows(t, first, last, frame, und, def, part[w]);
+  };
+  std::vector<std::thread> th;
+  for (size_t w = 1; w < workers; ++w)
+    th.emplace_back(work, w);
+  work(0);
+  for (std::thread &x : th)
+    x.join();
 }
 
 // the Lagrangian branch shared by adjust_rectangular/annular/blob_domain
@@ -517,13 +548,22 @@ int lk_tracker_get_results(const lk_tracker *t, lk_frame_result *out) {
 int lk_tracker_report(const lk_tracker *t, char *buf, size_t cap, size_t *needed) {
   if (!t)
     return LK_ERROR_BAD_DOMAIN;
-  const std::string &s = t->report;
+  size_t size = t->report.size();
+  for (const std::string &x : t->report_blocks)
+    size += x.size();
   if (needed)
-    *needed = s.size() + 1;
+    *needed = size + 1;
   if (buf && cap > 0) {
-    size_t n = s.size() < cap - 1 ? s.size() : cap - 1;
-    std::memcpy(buf, s.data(), n);
-    buf[n] = 0;
+    size_t at = 0;
+    auto put_block = [&](const std::string &x) {
+      const size_t n = std::min(x.size(), cap - 1 - at);
+      std::memcpy(buf + at, x.data(), n);
+      at += n;
+    };
+    put_block(t->report);
+    for (const std::string &x : t->report_blocks)
+      put_block(x);
+    buf[at] = 0;
   }
   return LK_ERROR_NONE;
 }

@@ -21,17 +21,22 @@ for f in range(F):
     xd, yd = ca.speckle.deform(xs, ys, wl.size, wl.size, p)
     frames.append(np.ascontiguousarray(ca.speckle._render_torch(wl.size, wl.size, xd, yd, amps, 2.5, "cuda")))
 c = wl.size / 2.0
-for name, mode, ref in (("eulerian/first", tk.DEF_EULERIAN, tk.REF_FIRST), ("lagrangian/previous", tk.DEF_LAGRANGIAN, tk.REF_PREVIOUS),
-                        ("strict_lagrangian/previous", tk.DEF_STRICT_LAGRANGIAN, tk.REF_PREVIOUS)):
+for name, mode, ref, report, host_rebuild in (
+        ("eulerian/first", tk.DEF_EULERIAN, tk.REF_FIRST, False, False),
+        ("eulerian/first + CSV report", tk.DEF_EULERIAN, tk.REF_FIRST, True, False),
+        ("lagrangian/previous", tk.DEF_LAGRANGIAN, tk.REF_PREVIOUS, False, False),
+        ("strict_lagrangian/previous", tk.DEF_STRICT_LAGRANGIAN, tk.REF_PREVIOUS, False, False),
+        ("strict_lagrangian/previous, lists rebuilt on the host", tk.DEF_STRICT_LAGRANGIAN, tk.REF_PREVIOUS, False, True)):
+    os.environ["LK_HOST_REWARP"] = "1" if host_rebuild else "0"
     e = ca.HipCorrelationEngine(fitting_model=wl.model, py_stop=wl.py_stop)
     t = tk.SequenceTracker(wl.model, tk.DOMAIN_RECT, mode, ref, tk.ERRMODE_CONTINUE, lib=e.lib)
     t.set_rect_domain(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, c, c, wl.hs, wl.vs)
-    t.enable_report(False)
+    t.enable_report(report)
     t0 = time.perf_counter()
     done = tk.run_sequence(e, t, frames)
     wall = time.perf_counter() - t0
     r = t.results()
     print(json.dumps({"mode": name, "pairs": done, "ms_per_pair_wall": 1e3 * wall / done,
                       "error_free_fraction": float((r["error_code"] == 0).mean()),
-                      "median_u_last": float(np.median(r["resulting_parameters"][:, 0]))}), flush=True)
+                      "median_u_last": float(np.nanmedian(r["resulting_parameters"][:, 0]))}), flush=True)
     e.close(), t.close()

@@ -696,6 +696,7 @@ def _report_table(text):
     (0, 0, 1, ca.FM_UV),            # rectangular, strict Lagrangian
     (1, 1, 1, ca.FM_UVQ),           # annular, Lagrangian
     (1, 0, 1, ca.FM_UVUXUYVXVY),    # annular, strict Lagrangian
+    (2, 0, 1, ca.FM_UVQ),           # blob, strict Lagrangian
     (2, 2, 0, ca.FM_UVUXUYVXVY),    # blob, Eulerian
     (2, 1, 1, ca.FM_UVUXUYVXVY),    # blob, Lagrangian
     (3, 1, 1, ca.FM_UVUXUYVXVY),    # rectangular, Lagrangian, a finer grid (11 x 9 sectors of 15 x 17 samples)
@@ -764,6 +765,65 @@ def test_sequence_tracking_against_manager_oracle(oracle, domain, deformation, r
         u = np.array([float(r[col["parameter_0"]]) for r in last])
         assert np.abs(u - 0.9 * (len(frames) - 1)).max() < 0.25
     e.close(), t.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("given_centers,model,py_stop", [(True, ca.FM_UVUXUYVXVY, 2), (False, ca.FM_UVQ, 2),
+                                                         (False, ca.FM_UV, 3), (True, ca.FM_U, 1)])
+def test_device_rebuilt_lists_equal_the_host_rebuild(monkeypatch, given_centers, model, py_stop):
+    """lk_rewarp_sectors rebuilds the moved sample lists on the device (warp, per-level
+    decimation as one compaction, mean centres); the host rebuild (LK_HOST_REWARP=1) is the
+    restated reference loop.  Lists, centres, per-level counts and the next solve's records must
+    be the same bits - over two moves and a partial restore."""
+    frames = ca.speckle.speckle_sequence(320, 288, 3, velocity=(0.7, -0.4), dilation=6e-4, seed=9)
+
+    def run(host):
+        monkeypatch.setenv("LK_HOST_REWARP", "1" if host else "0")
+        rng = np.random.default_rng(4)
+        e = ca.HipCorrelationEngine(fitting_model=model, py_stop=py_stop)
+        e.set_batch_invariant(True)
+        e.set_undeformed_image(frames[0])
+        e.set_deformed_image(frames[1])
+        e.resetPolygon_rect(0, 40, 50, 70, 75)
+        e.resetPolygon_annular(1, 40.0, 30.0, 0.3, 1.1, 150.0, 140.0, 1)
+        ang = 2 * np.pi * np.arange(9) / 9
+        e.resetPolygon_blob(2, np.stack([200 + 50 * np.cos(ang), 90 + 40 * np.sin(ang)], 1).astype(np.float32))
+        e.resetPolygon_rect(3, 100, 200, 104, 203)          # 5 x 4 samples: starved upper levels
+        pts = np.stack([rng.uniform(60, 250, 700), rng.uniform(60, 220, 700)], 1).astype(np.float32)
+        e.set_sector_points(4, pts, center=(155.25, 140.5))
+        e.resetPolygon_rect(5, 180, 160, 260, 250)
+        e.commit_sectors()
+        S = e.n_sectors
+        out = []
+        g = np.zeros((S, 6), np.float32)
+        g[:, 0], g[:, 1] = 0.5, -0.25
+        for k in range(2):
+            r = e.correlate_all(g)
+            # (no host-side query here: the second move must find the first one's lists on the device)
+            centers = np.stack([np.trunc(r["und_cx"] + r["p"][:, 0] + 0.5), np.trunc(r["und_cy"] + 0.5)],
+                               1).astype(np.float32) if given_centers else None
+            e.rewarp_sectors(centers)
+            counts = [[e.sector_level_count(s, l) for l in range(py_stop + 1)] for s in range(S)]
+            if k == 0:      # the lists stay on the device between the frames of a sequence
+                e.makeUndPyramidFromDef()
+                e.set_deformed_image(frames[2])
+                out.append((r.tobytes(), counts))
+                continue
+            lists = [e.getUndXY0ToCPU(s).tobytes() for s in range(S)]
+            out.append((r.tobytes(), counts, lists, [e.sector_info(s) for s in range(S)]))
+        r = e.correlate_all(g)
+        out.append(r.tobytes())
+        e.restore_sectors(2)        # sectors 2.. go back to the lists of the second frame
+        out.append([e.getUndXY0ToCPU(s).tobytes() for s in range(S)])
+        out.append([[e.sector_level_count(s, l) for l in range(py_stop + 1)] for s in range(S)])
+        out.append(e.correlate_all(g).tobytes())
+        e.close()
+        return out
+
+    want, got = run(True), run(False)
+    assert len(want) == len(got)
+    for i, (w, g) in enumerate(zip(want, got)):
+        assert w == g, f"stage {i}"
 
 
 @pytest.mark.gpu

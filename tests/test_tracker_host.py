@@ -171,6 +171,45 @@ def test_tracker_stop_policy(oracle, engine_lib, frames):
         t.close()
 
 
+def test_report_of_a_large_grid_is_in_sector_order(engine_lib):
+    """Grids of thousands of sectors format their report rows on several threads: the text must
+    be the sequential loop's (manager_class.cpp:2430-2471), row for row."""
+    t = tk.SequenceTracker(ca.FM_UVQ, tk.DOMAIN_RECT, tk.DEF_EULERIAN, tk.REF_FIRST, tk.ERRMODE_CONTINUE,
+                           lib=engine_lib)
+    t.set_rect_domain(20.0, 24.0, 2027.0, 2023.0, 1024.0, 1024.0, 90, 80)
+    S = t.n_sectors
+    assert S == 7200
+    rng = np.random.default_rng(5)
+    want = []
+    for k in range(2):
+        cmds, guesses = t.begin_frame(k)
+        res = np.zeros(S, ca.RESULT_DTYPE)
+        res["p"][:, :3] = rng.normal(0, 1.5, (S, 3)).astype(np.float32) * np.float32([1, 1, 1e-2])
+        res["chi"] = rng.uniform(0.5, 900.0, S).astype(np.float32)
+        res["n_points"] = rng.integers(1, 500, S)
+        res["iterations"] = rng.integers(1, 40, S)
+        res["error_code"] = np.where(rng.random(S) < 0.02, ca.ERROR_CORRELATION_MAX_ITERS_REACHED, 0)
+        res["und_cx"], res["und_cy"] = cmds["center_x"], cmds["center_y"]
+        first, stop = t.end_frame(k, f"und{k}", f"def{k}", res)
+        assert first == S and not stop
+        got = t.results()
+        for s in range(S):
+            r = got[s]
+            v = [mo.fmt(k), f"und{k}", f"def{k}"]
+            v += [mo.fmt(r[n]) for n in ("und_global_center_x", "und_global_center_y", "und_center_x", "und_center_y",
+                                         "def_global_center_x", "def_global_center_y", "def_center_x", "def_center_y")]
+            v += [mo.fmt(x) for x in r["resulting_parameters"][:3]] + [mo.fmt(x) for x in r["initial_guess"][:3]]
+            v += [mo.fmt(r[n]) for n in ("und_global_angle", "def_global_angle", "und_angle", "def_angle")]
+            v += [mo.fmt(np.float32(np.float32(r["def_angle"] * np.float32(180)) / mo.PI)), mo.fmt(r["chi"]),
+                  mo.fmt(int(r["number_of_points"])), mo.fmt(int(r["iterations"])), mo.fmt(bool(r["error_status"])),
+                  mo.fmt(int(r["error_code"]))]
+            want.append(",".join(v))
+    rows = t.report().split("\n")
+    assert rows[-1] == "" and len(rows) == 2 + 2 * S
+    assert rows[1:-1] == want
+    t.close()
+
+
 def test_pgm_loader(engine_lib, tmp_path):
     rng = np.random.default_rng(2)
     img = rng.integers(0, 256, (37, 53), dtype=np.uint8)
