@@ -53,14 +53,88 @@ struct lk_tracker {
 // std::ostream << float / int / bool with default flags, which is what the reference's report
 // stream does: "%g" with 6 significant digits == std::to_chars(general, 6); an ostringstream
 // round trip per number would cost more than the solve on 50 000-sector grids.
-static void put(std::string &r, float v) {
+//
+// Fast path: the float is widened to double (exact), scaled to a 6-digit integer by ONE
+// correctly rounded multiplication or division with an exact power of ten (|error| < 2e-10),
+// and rounded; whenever that product is within 1e-6 of a rounding boundary - which includes
+// every exact tie - or the decade is outside the exact powers, std::to_chars decides.
+static const double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                  1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+
+static void put_slow(std::string &r, float v) {
   char buf[48];
+  auto res = std::to_chars(buf, buf + sizeof(buf), v, std::chars_format::general, 6);
+  r.append(buf, res.ptr);
+}
+
+static void put(std::string &r, float v) {
   if (std::isnan(v)) { // num_put prints what printf does
     r += std::signbit(v) ? "-nan" : "nan";
     return;
   }
-  auto res = std::to_chars(buf, buf + sizeof(buf), v, std::chars_format::general, 6);
-  r.append(buf, res.ptr);
+  const double a = std::fabs((double)v);
+  if (!(a >= 1e-16 && a < 1e16)) { // zero, infinities, far decades
+    put_slow(r, v);
+    return;
+  }
+  int k = (int)std::floor(std::log10(a)); // decade estimate, corrected against the exact table
+  if (k >= 0 ? a < kPow10[k] : a < 1.0 / kPow10[-k])
+    --k; // (1/10^n is inexact: the boundary test below still sends doubtful cases to to_chars)
+  const int shift = 5 - k; // digits = a * 10^shift in [1e5, 1e6)
+  if (shift > 22 || shift < -22) {
+    put_slow(r, v);
+    return;
+  }
+  const double scaled = shift >= 0 ? a * kPow10[shift] : a / kPow10[-shift];
+  const double fl = std::floor(scaled), frac = scaled - fl;
+  if (!(scaled >= 100000.0 && scaled < 999999.0) || std::fabs(frac - 0.5) < 1e-6) {
+    put_slow(r, v);
+    return;
+  }
+  uint32_t digits = (uint32_t)fl + (frac > 0.5 ? 1u : 0u); // 100000 .. 999999
+  char d[6];
+  for (int i = 5; i >= 0; --i) {
+    d[i] = (char)('0' + digits % 10);
+    digits /= 10;
+  }
+  int nd = 6;
+  while (nd > 1 && d[nd - 1] == '0')
+    --nd; // %g drops trailing zeros
+  char buf[24];
+  char *o = buf;
+  if (std::signbit(v))
+    *o++ = '-';
+  if (k >= -4 && k < 6) { // fixed notation
+    if (k >= 0) {
+      for (int i = 0; i <= k; ++i)
+        *o++ = i < nd ? d[i] : '0';
+      if (nd > k + 1) {
+        *o++ = '.';
+        for (int i = k + 1; i < nd; ++i)
+          *o++ = d[i];
+      }
+    } else {
+      *o++ = '0';
+      *o++ = '.';
+      for (int i = -1; i > k; --i)
+        *o++ = '0';
+      for (int i = 0; i < nd; ++i)
+        *o++ = d[i];
+    }
+  } else { // d.ddddde+XX
+    *o++ = d[0];
+    if (nd > 1) {
+      *o++ = '.';
+      for (int i = 1; i < nd; ++i)
+        *o++ = d[i];
+    }
+    *o++ = 'e';
+    *o++ = k < 0 ? '-' : '+';
+    const int ak = k < 0 ? -k : k;
+    *o++ = (char)('0' + ak / 10);
+    *o++ = (char)('0' + ak % 10);
+  }
+  r.append(buf, o);
 }
 static void put(std::string &r, int v) {
   char buf[16];
@@ -148,8 +222,10 @@ static void add_frame_to_report(lk_tracker *t, int frame, const char *und, const
   std::string *part = &t->report_blocks[base];
   auto work = [=](size_t w) {
     const size_t first = S * w / workers, last = S * (w + 1) / workers;
-    part[w].reserve((last - first) * (size_t)(96 + 26 * t->P) + 64);
-    report_rows(t, first, last, frame, und, def, part[w]);
+    std::string rows; // (a local: the block headers sit side by side in one cache line)
+    rows.reserve((last - first) * (size_t)(96 + 26 * t->P) + 64);
+    report_rows(t, first, last, frame, und, def, rows);
+    part[w] = std::move(rows);
   };
   std::vector<std::thread> th;
   for (size_t w = 1; w < workers; ++w)

@@ -185,6 +185,17 @@ def test_report_of_a_large_grid_is_in_sector_order(engine_lib):
         cmds, guesses = t.begin_frame(k)
         res = np.zeros(S, ca.RESULT_DTYPE)
         res["p"][:, :3] = rng.normal(0, 1.5, (S, 3)).astype(np.float32) * np.float32([1, 1, 1e-2])
+        # the number formatter: every decade from 1e-30 to 1e30, random mantissas, and values
+        # on or next to a rounding boundary of the sixth digit
+        wild = (rng.integers(27, 227, 3 * 3000).astype(np.uint32) << 23 | rng.integers(0, 1 << 23, 3 * 3000).astype(np.uint32)
+                | rng.integers(0, 2, 3 * 3000).astype(np.uint32) << 31).view(np.float32)
+        res["p"][:3000, :3] = wild.reshape(3000, 3)
+        edge = np.float32([1234565.0, 0.5, 2.5, 1e5, 999999.5, 9.999995, 100000.5, 1e-5, 1e-4, 1.234565e-5, 999999.0,
+                           999999.44, 1e6, 123456.5, 123457.5, 0.000123456, 16777216.0, 1e-16, 1e16, 3.0000002e-20,
+                           8388608.5, 0.1, 0.3, 1.0, 10.0, 99999.95, 0.999999, 0.9999995, 1.5e-5, 4.5, 1e22, 1e23])
+        edge = np.concatenate([edge, np.nextafter(edge, np.float32(np.inf)), np.nextafter(edge, np.float32(0)), -edge])
+        edge = np.resize(edge, 3 * ((len(edge) + 2) // 3))
+        res["p"][3000:3000 + len(edge) // 3, :3] = edge.reshape(-1, 3)
         res["chi"] = rng.uniform(0.5, 900.0, S).astype(np.float32)
         res["n_points"] = rng.integers(1, 500, S)
         res["iterations"] = rng.integers(1, 40, S)
