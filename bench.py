@@ -164,6 +164,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sectors", type=int, default=10000)
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="image pairs in flight per GPU: step k runs on engine k %% INFLIGHT, each engine on its own "
+                         "HIP stream, so the straggler tail of one solve is filled by the next pair's solve "
+                         "(1: strictly one pair at a time - the 'sequential' block of the default output)")
     ap.add_argument("--workload", default="C2", choices=["C2", "C4", "C4B", "C5"],
                     help="C2 (default, the headline: weak scaling, every rank its own 10k-sector grid); "
                          "C4 / C4B / C5: ONE pair of that config with its sector grid sharded over the ranks "
@@ -200,61 +204,95 @@ def main():
     d_und = torch.from_numpy(und).to(dev)
     d_def = torch.from_numpy(dfm).to(dev) if rank == 0 else torch.empty_like(d_und)
 
-    e = ca.HipCorrelationEngine(interpolation=ca.IM_BICUBIC, fitting_model=wl.model, py_stop=wl.py_stop,
-                                device=local_rank)
-    # a dedicated (non-null) HIP stream shared by torch, RCCL and the engine: torch events
-    # recorded on it bracket exactly the engine's launches
-    stream = torch.cuda.Stream(dev)
-    torch.cuda.set_stream(stream)
-    assert stream.cuda_stream != 0
-    e.set_stream(stream.cuda_stream)
-    if strong:   # one grid, contiguous blocks of the sector index per rank
-        first, count = shard_range(wl.hs * wl.vs, rank, world)
-        e.set_rect_grid(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, wl.hs, wl.vs, first, count)
-    else:        # weak scaling: rank r correlates the C2 grid shifted by r px (same sector size, distinct ROIs)
-        e.set_rect_grid(wl.x_begin + rank, wl.x_begin + rank, wl.x_end + rank - 8 * (world > 1),
-                        wl.x_end + rank - 8 * (world > 1), wl.hs, wl.vs)
-    e.commit_sectors()
+    P = max(1, args.inflight)
+
+    def make_engine(pairs_in_flight):
+        # a dedicated (non-null) HIP stream shared by torch, RCCL and the engine: torch events
+        # recorded on it bracket exactly the engine's launches
+        eng = ca.HipCorrelationEngine(interpolation=ca.IM_BICUBIC, fitting_model=wl.model, py_stop=wl.py_stop,
+                                      device=local_rank)
+        st_ = torch.cuda.Stream(dev)
+        assert st_.cuda_stream != 0
+        eng.set_stream(st_.cuda_stream)
+        eng.set_pairs_in_flight(pairs_in_flight)
+        if strong:   # one grid, contiguous blocks of the sector index per rank
+            first, count = shard_range(wl.hs * wl.vs, rank, world)
+            eng.set_rect_grid(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, wl.hs, wl.vs, first, count)
+        else:        # weak scaling: rank r correlates the C2 grid shifted by r px (same sector size, distinct ROIs)
+            eng.set_rect_grid(wl.x_begin + rank, wl.x_begin + rank, wl.x_end + rank - 8 * (world > 1),
+                              wl.x_end + rank - 8 * (world > 1), wl.hs, wl.vs)
+        eng.commit_sectors()
+        eng.set_timing(False)   # the engine's own per-call HIP events stay out of the timed frames
+        return eng, st_
+
+    # one engine per pair in flight; `e` (one pair at a time) measures the single launch
+    lanes = [make_engine(P) for _ in range(P)]
+    e, stream = make_engine(1) if P > 1 else lanes[0]
     S = e.n_sectors
     S_cap = (wl.hs * wl.vs + world - 1) // world if strong else S   # equal all-gather blocks
     n0 = e.sector_info(0)[0]
     d_guess = torch.zeros((S, 6), dtype=torch.float32, device=dev)
-    # double buffers: the broadcast of frame k+1 and the gather of the records of frame k
-    # run on RCCL's streams while frame k / k+1 is being solved (the reference prefetches the
-    # next frame the same way, manager_class.cpp:1438-1447)
-    d_defs = [d_def, d_def.clone()]
-    d_ress = [torch.zeros((S_cap, 48), dtype=torch.uint8, device=dev) for _ in range(2)]
-    d_alls = [torch.empty((world * S_cap, 48), dtype=torch.uint8, device=dev) for _ in range(2)] if use_dist else None
-    pending = {"bcast": None, "gather": [None, None], "k": 0}
+    # Steps are dealt to the lanes in rounds of P.  The P frames of round m+1 travel in ONE
+    # broadcast while round m is being solved, and the P record blocks of round m leave in ONE
+    # all-gather once its solves are done (the reference prefetches the next frame the same
+    # way, manager_class.cpp:1438-1447): two collectives per round keep the host out of the way
+    # (one broadcast and one gather per step cost ~0.2 ms of host time per step - more than a
+    # step takes on the GPU).  Two sets of buffers alternate between rounds.
+    d_defs = [torch.stack([d_def] * P) for _ in range(2)]                       # [2][P, H, W]
+    d_ress = [torch.zeros((P, S_cap, 48), dtype=torch.uint8, device=dev) for _ in range(2)]
+    d_alls = [torch.empty((world, P, S_cap, 48), dtype=torch.uint8, device=dev) for _ in range(2)] if use_dist else None
+    solved = [torch.cuda.Event() for _ in range(P)]     # lane j's latest solve
+    pending = {"bcast": [None, None], "gather": [None, None], "k": 0}
 
-    def prefetch(k):  # frame k -> d_defs[k % 2], over RCCL / xGMI
-        return dist.broadcast(d_defs[k % 2], src=0, async_op=True) if use_dist else None
+    def after_all_lanes(st_):   # st_ continues after the latest solve of every lane
+        for ev in solved:
+            st_.wait_event(ev)
 
-    pending["bcast"] = prefetch(0)
+    def prefetch(m):   # frames of round m -> d_defs[m % 2], over RCCL / xGMI
+        return dist.broadcast(d_defs[m % 2], src=0, async_op=True) if use_dist else None
+
+    def gather(m):     # warp parameters of round m
+        return dist.all_gather_into_tensor(d_alls[m % 2].view(-1, 48), d_ress[m % 2].view(-1, 48), async_op=True)
+
+    torch.cuda.set_stream(lanes[0][1])
+    pending["bcast"][0] = prefetch(0)
 
     def step():
         k = pending["k"]
+        m, j = divmod(k, P)
+        eng, st_ = lanes[j]
+        torch.cuda.set_stream(st_)   # RCCL orders its work against torch's current stream: the lane's own
         if use_dist:
-            pending["bcast"].wait()                      # frame k has arrived
-            pending["bcast"] = prefetch(k + 1)           # frame k+1 travels during this solve
-            if pending["gather"][k % 2] is not None:
-                pending["gather"][k % 2].wait()          # records of frame k-2 have left d_ress[k % 2]
+            pending["bcast"][m % 2].wait()               # the frames of round m have arrived
+            if j == 0:
+                after_all_lanes(st_)                     # round m-1 no longer reads the other frame set
+                pending["bcast"][(m + 1) % 2] = prefetch(m + 1)   # round m+1 travels during this one
+            if pending["gather"][m % 2] is not None:
+                pending["gather"][m % 2].wait()          # the records of round m-2 have left d_ress[m % 2]
         # upload + pyramid build of both frames of the pair (one launch, CudaClass::resetImagePyramids)
-        e.set_image_pair_device(d_und.data_ptr(), d_defs[k % 2].data_ptr(), wl.size, wl.size)
-        e.correlate_all_device(d_guess.data_ptr(), d_ress[k % 2].data_ptr())          # the solve
-        if use_dist:                                     # gather of warp parameters
-            pending["gather"][k % 2] = dist.all_gather_into_tensor(d_alls[k % 2], d_ress[k % 2], async_op=True)
+        eng.set_image_pair_device(d_und.data_ptr(), d_defs[m % 2][j].data_ptr(), wl.size, wl.size)
+        eng.correlate_all_device(d_guess.data_ptr(), d_ress[m % 2][j].data_ptr())     # the solve
+        if use_dist:
+            solved[j].record(st_)
+            if j == P - 1:
+                after_all_lanes(st_)
+                pending["gather"][m % 2] = gather(m)
         pending["k"] = k + 1
 
     def fence():
         if use_dist:
+            m, j = divmod(pending["k"], P)
+            if j != 0:                                   # a round cut short by the end of the timed region
+                st_ = lanes[j - 1][1]
+                torch.cuda.set_stream(st_)
+                after_all_lanes(st_)
+                pending["gather"][m % 2] = gather(m)
             for w in pending["gather"]:
                 if w is not None:
                     w.wait()
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    e.set_timing(False)  # the engine's own per-call HIP events stay out of the timed frames
     for _ in range(args.warmup):
         step()
     fence()
@@ -263,29 +301,60 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
+    m_last, j_last = divmod(pending["k"] - 1, P)
+    res = d_ress[m_last % 2][j_last][:S].cpu().numpy().view(ca.RESULT_DTYPE).reshape(-1)   # the last timed step's records
+    eng0 = lanes[0][0]
+    eng0.set_timing(True)
+    eng0.set_image_device(ca.IMG_DEF, d_defs[0][0].data_ptr(), wl.size, wl.size)
+    eng0.correlate_all_device(d_guess.data_ptr(), d_ress[0][0].data_ptr())   # untimed: fills lk_stats
+    torch.cuda.synchronize(dev)
+    st_lanes = eng0.stats()   # counters of one solve of the engines the timed region ran on
+
+    # one pair at a time on `e`: the same step, strictly sequential, and the single launch
+    torch.cuda.set_stream(stream)
+
+    def seq_step():
+        e.set_image_pair_device(d_und.data_ptr(), d_defs[0][0].data_ptr(), wl.size, wl.size)
+        e.correlate_all_device(d_guess.data_ptr(), d_ress[0][0].data_ptr())
+
+    for _ in range(min(args.warmup, 10)):
+        seq_step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        seq_step()
+    torch.cuda.synchronize(dev)
+    dt_seq = time.perf_counter() - t0
     e.set_timing(True)
-    e.set_image_device(ca.IMG_DEF, d_defs[0].data_ptr(), wl.size, wl.size)
-    e.correlate_all_device(d_guess.data_ptr(), d_ress[0].data_ptr())   # untimed: fills lk_stats' event times
+    e.set_image_device(ca.IMG_DEF, d_defs[0][0].data_ptr(), wl.size, wl.size)
+    e.correlate_all_device(d_guess.data_ptr(), d_ress[0][0].data_ptr())   # untimed: fills lk_stats' event times
     st = e.stats()   # counters + the engine's own HIP-event time of the LAST solve launch
-    # per-launch duration of the dominant kernel, measured live with HIP events on the
-    # stream it runs on: K back-to-back solve launches bracketed by two events
+    # per-launch duration of the dominant kernel running alone, measured live with HIP events on
+    # the stream it runs on: K back-to-back solve launches bracketed by two events
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
     for _ in range(args.steps):
-        e.correlate_all_device(d_guess.data_ptr(), d_ress[0].data_ptr())
+        e.correlate_all_device(d_guess.data_ptr(), d_ress[0][0].data_ptr())
     e1.record(stream)
     torch.cuda.synchronize(dev)
     solve_avg_ms = e0.elapsed_time(e1) / args.steps
+    # ... and with P pairs in flight: K solve launches dealt to the lanes, first start to last end
+    torch.cuda.set_stream(lanes[0][1])
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        lanes[k % P][0].correlate_all_device(d_guess.data_ptr(), d_ress[(k // P) % 2][k % P].data_ptr())
+    torch.cuda.synchronize(dev)
+    solve_overlapped_ms = (time.perf_counter() - t0) / args.steps * 1e3
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    pit = torch.tensor([float(st["point_iterations"])], dtype=torch.float64, device=dev)
+    pit = torch.tensor([float(st_lanes["point_iterations"])], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(pit, op=dist.ReduceOp.SUM)
     dt_max = float(tmax.item())
     total_pit = float(pit.item()) * args.steps
 
-    res = d_ress[0][:S].cpu().numpy().view(ca.RESULT_DTYPE).reshape(-1)
     if rank == 0:
         value = total_pit / dt_max
         achieved = st["algorithmic_bytes"] / (solve_avg_ms * 1e-3) / 1e9
@@ -314,7 +383,12 @@ def main():
             "config": {"workload": wl.name, "sectors_per_gpu": S, "sectors_total": wl.hs * wl.vs if strong else S * world,
                        "samples_per_sector": n0,
                        "interpolation": "bicubic", "parallelism": f"sectors sharded x{world}",
-                       "step": "pyramid(und)+pyramid(def)+solve, inputs resident in HBM"},
+                       "pairs_in_flight": P,
+                       "step": "pyramid(und)+pyramid(def)+solve of one pair, inputs resident in HBM; step k runs on "
+                               f"engine k % {P} (own HIP stream), so up to {P} independent pairs overlap on the GPU"},
+            # the same step with one pair at a time (bench.py --inflight 1): the latency of a pair
+            "sequential": {"pairs_in_flight": 1, "value": float(st["point_iterations"]) * args.steps / dt_seq,
+                           "ms_per_step": 1e3 * dt_seq / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": ("lk_solve_kernel<fm_UVUxUyVxVy, im_bicubic> (32-lane groups, 2 sectors per wavefront; the events "
@@ -323,17 +397,23 @@ def main():
                                     "lk_solve_kernel<fm_UVUxUyVxVy, im_bicubic>: all launches of one solve "
                                     "(one-lane starved-level kernel, finisher, 16-lane groups)"),
                          "kernel_ms": solve_avg_ms,
-                         "algorithmic_bytes_per_launch": st["algorithmic_bytes"]},
+                         "measured": "the kernel running alone: K back-to-back launches of one engine between two HIP "
+                                     "events on its stream (rocprofv3 of `bench.py --inflight 1` agrees)",
+                         "algorithmic_bytes_per_launch": st["algorithmic_bytes"],
+                         # K launches dealt to the P engines: (last end - first start) / K
+                         "with_pairs_in_flight": {"pairs": P, "ms_per_launch": solve_overlapped_ms,
+                                                  "achieved": st_lanes["algorithmic_bytes"] / (solve_overlapped_ms * 1e-3) / 1e9,
+                                                  "frac": st_lanes["algorithmic_bytes"] / (solve_overlapped_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
             "per_pair": {"sectors_per_s": (wl.hs * wl.vs if strong else S * world) * args.steps / dt_max,
-                         "evaluations": st["evaluations"], "sample_evaluations": st["sample_evaluations"],
-                         "point_iterations": st["point_iterations"],
-                         "mean_point_iterations_per_sector": st["point_iterations"] / S,
+                         "evaluations": st_lanes["evaluations"], "sample_evaluations": st_lanes["sample_evaluations"],
+                         "point_iterations": st_lanes["point_iterations"],
+                         "mean_point_iterations_per_sector": st_lanes["point_iterations"] / S,
                          "error_free_fraction": float((res["error_code"] == 0).mean()),
                          "last_solve_ms": st["solve_ms"], "last_pyramid_ms": st["pyramid_ms"]},
         }
         if world == 1 and not args.no_cpu_baseline and not strong:
             base, nsec = cpu_baseline(wl, und, dfm, args.cpu_sectors)
-            pit_per_sector = st["point_iterations"] / S
+            pit_per_sector = st_lanes["point_iterations"] / S
             rate_mt, dt_mt, thr_mt, res_mt = base["all_cores"]
             rate_1, dt_1, _, res_1 = base["1_thread"]
             line["cpu_baseline"] = {
@@ -352,10 +432,12 @@ def main():
                 "iterations_equal_fraction": float((res["iterations"][xs] == res_1["iterations"]).mean()),
             }
         if world == 1 and not args.no_other_configs and not use_dist and not strong:
-            e.close()
+            for eng in {id(x): x for x in [e] + [l[0] for l in lanes]}.values():
+                eng.close()
             line["other_configs"] = other_configs(ca)
         print(json.dumps(line))
-    e.close()
+    for eng in {id(x): x for x in [e] + [l[0] for l in lanes]}.values():
+        eng.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -133,6 +133,7 @@ struct lk_engine {
   hipEvent_t nxt_done = nullptr, ev_s0 = nullptr, ev_s1 = nullptr, ev_p0 = nullptr, ev_p1 = nullptr;
   bool nxt_pending = false, solve_timed = false, pyr_timed = false;
   bool batch_invariant = false; // lk_set_batch_invariant
+  int pairs_in_flight = 1;      // lk_set_pairs_in_flight: launches that share the GPU
   bool timing = true; // HIP events around pyramid builds and solves (lk_stats.solve_ms / pyramid_ms)
   std::mutex nxt_mu;
   std::string err;
@@ -279,6 +280,8 @@ void lk_destroy(lk_engine *e) {
   e->d_ill_count.release();
   e->d_scratch.release();
   e->d_warp.release();
+  e->d_team_partials.release();
+  e->d_team_arrivals.release();
   if (e->own_stream)
     (void)hipStreamDestroy(e->own_stream);
   if (e->nxt_stream)
@@ -311,6 +314,15 @@ int lk_set_batch_invariant(lk_engine *e, int enabled) {
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
   e->batch_invariant = enabled != 0;
+  return LK_ERROR_NONE;
+}
+
+int lk_set_pairs_in_flight(lk_engine *e, int n) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (n < 1 || n > 64)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_pairs_in_flight: n must be in 1..64");
+  e->pairs_in_flight = n;
   return LK_ERROR_NONE;
 }
 
@@ -811,13 +823,16 @@ static int commit_impl(lk_engine *e, bool keep_state) {
   for (int c = 0; c + 1 < kTeamClass; ++c) { // (nothing is promoted into the team class)
     if (!cnt[c] || e->batch_invariant) // batch-invariant records: the group depends on the sector alone
       continue;
-    // Wavefronts are dealt to SIMD slots as earlier ones retire; that only balances the
-    // uneven per-sector iteration counts when there are a few times more wavefronts than
-    // slots (1024 SIMDs x ~3).  Otherwise use wider groups: fewer sectors per wavefront.
-    size_t waves = cnt[c] * (size_t)kGroupOfClass[c] / 64;
+    // Wider groups shorten a sector's own critical path and cost lane packing: they pay only
+    // while the narrow grouping leaves SIMDs without a wavefront (fewer wavefronts than the
+    // 1024 SIMDs).  Measured on 19x19-sample sectors (scripts/quick_solve.py, LK_GRID /
+    // LK_FORCE_GROUP): 1024 sectors 0.110 ms in 32-lane groups against 0.092 ms in 64-lane ones,
+    // 2025 sectors 0.122 / 0.123, 4096 sectors 0.166 / 0.188, 8100 sectors 0.240 / 0.324.
+    size_t waves = cnt[c] * (size_t)kGroupOfClass[c] / 64 * (size_t)e->pairs_in_flight; // (the other launches' too)
     size_t per_lane = tot[c] / cnt[c] / (size_t)kGroupOfClass[c];
     const bool small_group = kGroupOfClass[c] < 64;
-    if ((small_group && waves < 4096 && per_lane >= 4) || (!small_group && waves < 2048 && per_lane >= 32)) {
+    const size_t enough = kGroupOfClass[c] == 16 ? 4096 : 1024; // (16-lane groups: 10 000 sectors 0.31 against 0.27 ms)
+    if ((small_group && waves < enough && per_lane >= 4) || (!small_group && waves < 2048 && per_lane >= 32)) {
       for (int s = 0; s < S; ++s)
         if (e->h_class[(size_t)s] == c)
           e->h_class[(size_t)s] = c + 1;

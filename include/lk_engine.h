@@ -119,6 +119,14 @@ int lk_set_timing(lk_engine *e, int enabled);
  * the batch's): a sector then gets the same bits in any batch, shard or single-sector call
  * (about 20 % slower on small grids).  Call it before lk_commit_sectors. */
 int lk_set_batch_invariant(lk_engine *e, int enabled);
+/* Independent image pairs can be solved side by side: one engine per pair in flight, each on
+ * its own stream (lk_set_stream).  A solve ends in a tail of slow sectors that leaves most of
+ * the GPU idle; the next pair's solve fills it (C2: 0.26 ms per pair one at a time, 0.15 ms
+ * with three in flight).  n tells the engine how many launches share the GPU so that it keeps
+ * the narrow, better-packed lane groups it would otherwise widen to shorten a lone solve
+ * (default 1).  Call it before lk_commit_sectors.  Tracked sequences cannot use this: the
+ * guess of pair k+1 needs the result of pair k (manager_class.cpp:2602-2707). */
+int lk_set_pairs_in_flight(lk_engine *e, int n);
 /* block until everything queued by this engine has finished */
 int lk_synchronize(lk_engine *e);
 

@@ -23,7 +23,12 @@ e = ca.HipCorrelationEngine(fitting_model=wl.model, py_stop=wl.py_stop,
                             interpolation=int(os.environ.get("LK_INTERP", ca.IM_BICUBIC)))
 e.set_undeformed_image(und)
 e.set_deformed_image(dfm)
-e.set_rect_grid(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, wl.hs, wl.vs)
+grid = int(os.environ.get("LK_GRID", 0))   # tuning: another number of sectors of the same size
+if grid:
+    pitch = (wl.x_end - wl.x_begin + 1) / wl.hs
+    e.set_rect_grid(wl.x_begin, wl.x_begin, wl.x_begin + grid * pitch - 1, wl.x_begin + grid * pitch - 1, grid, grid)
+else:
+    e.set_rect_grid(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, wl.hs, wl.vs)
 e.commit_sectors()
 g = np.zeros(6, np.float32)
 r = e.correlate_all(g)
@@ -33,6 +38,6 @@ for _ in range(n):
     ms.append(e.stats()["solve_ms"])
 st = e.stats()
 ms = np.array(ms)
-print(f"{wl.name}\n solve_ms min {ms.min():.4f} median {np.median(ms):.4f}  pit/s {st['point_iterations'] / (np.median(ms) * 1e-3):.3e}"
+print(f"{wl.name}" + (f" [grid {grid}x{grid}, {e.sector_info(0)[0]} samples per sector]" if grid else "") + f"\n solve_ms min {ms.min():.4f} median {np.median(ms):.4f}  pit/s {st['point_iterations'] / (np.median(ms) * 1e-3):.3e}"
       f"  alg GB/s {st['algorithmic_bytes'] / (np.median(ms) * 1e-3) / 1e9:.1f}  frac {st['algorithmic_bytes'] / (np.median(ms) * 1e-3) / 8e12:.4f}"
       f"  evals/sector {st['evaluations'] / st['sectors']:.2f}  ill {st['ill_conditioned_solves']}  errfree {(r['error_code'] == 0).mean():.4f}")

@@ -203,6 +203,78 @@ def test_pyramid_from_device_frames_bit_exact(oracle):
         e.close()
 
 
+def test_pairs_in_flight_give_the_records_of_a_lone_solve(speckle512):
+    """Independent pairs solved side by side - one engine per pair, each on its own stream, all
+    launches queued before any has finished (bench.py --inflight) - must give every pair the
+    records it gets alone; the lk_set_pairs_in_flight hint only picks the lane group."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    hip.hipStreamCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+    hip.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    und, dfm = speckle512
+    pairs = [(und, dfm), (dfm, und), (und, np.ascontiguousarray(np.roll(dfm, 1, axis=1)))]
+
+    def dev(a):
+        d = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(d), a.size) == 0
+        assert hip.hipMemcpy(d, a.ctypes.data_as(ctypes.c_void_p), a.size, 1) == 0
+        return d
+
+    frames = [(dev(a), dev(b)) for a, b in pairs]
+    S = 40 * 40
+    d_guess, d_res = dev(np.zeros(S * 24, np.uint8)), [dev(np.zeros(S * 48, np.uint8)) for _ in pairs]
+
+    def engine(in_flight, stream=None):
+        e = ca.HipCorrelationEngine()
+        e.set_batch_invariant(True)        # the same bits whatever the neighbours on the GPU do
+        e.set_pairs_in_flight(in_flight)
+        if stream is not None:
+            e.set_stream(stream.value)
+        e.set_rect_grid(16.0, 16.0, 495.0, 495.0, 40, 40)
+        e.commit_sectors()
+        return e
+
+    def fetch(d):
+        out = np.zeros(S, ca.RESULT_DTYPE)
+        assert hip.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), d, out.nbytes, 2) == 0
+        return out
+
+    alone = []
+    e = engine(1)
+    for (a, b), r in zip(frames, d_res):
+        e.set_image_pair_device(a.value, b.value, 512, 512)
+        e.correlate_all_device(d_guess.value, r.value)
+        e.synchronize()
+        alone.append(fetch(r))
+    e.close()
+    assert (alone[0]["error_code"] == 0).all() and not np.array_equal(alone[0]["p"], alone[1]["p"])
+    streams, engines = [], []
+    for _ in pairs:
+        st = ctypes.c_void_p()
+        assert hip.hipStreamCreateWithFlags(ctypes.byref(st), 1) == 0     # hipStreamNonBlocking
+        streams.append(st)
+        engines.append(engine(len(pairs), st))
+    for rep in range(3):                                                  # 9 launches queued back to back
+        for e, (a, b), r in zip(engines, frames, d_res):
+            e.set_image_pair_device(a.value, b.value, 512, 512)
+            e.correlate_all_device(d_guess.value, r.value)
+    for e in engines:
+        e.synchronize()
+    for k, r in enumerate(d_res):
+        got = fetch(r)
+        assert got.tobytes() == alone[k].tobytes(), f"pair {k}"
+    for e, st in zip(engines, streams):
+        e.close()
+        assert hip.hipStreamDestroy(st) == 0
+    for d in [x for f in frames for x in f] + [d_guess] + d_res:
+        assert hip.hipFree(d) == 0
+    with pytest.raises(ca.LkError):
+        ca.HipCorrelationEngine().set_pairs_in_flight(0)
+
+
 @pytest.mark.parametrize("interp", [ca.IM_NEAREST, ca.IM_BILINEAR, ca.IM_BICUBIC])
 def test_sampling_bit_exact(oracle, speckle512, interp):
     und, dfm = speckle512
