@@ -12,6 +12,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <charconv>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <future>
 #include <sstream>
 #include <string>
@@ -25,6 +28,89 @@ const float kPI = 3.14159265359f; // parameters.hpp:23
 
 int n_params(int model) { return model == LK_FM_U ? 1 : model == LK_FM_UV ? 2 : model == LK_FM_UVQ ? 3 : 6; }
 } // namespace
+
+// The per-sector loops of a frame (positions and guesses, update_results, report rows) touch
+// one frame_results record each: on grids of tens of thousands of sectors they take longer
+// than the solve itself (50 176 sectors: 1.6 + 1.6 ms against 2.3 ms on the GPU), so they are
+// split into blocks of sectors over a few helper threads that live as long as the tracker.
+// Anything order-dependent (the float sums of update_global_results, the first-error scan of
+// the stop policy, the order of the report rows) stays sequential or is joined in sector order.
+class Workers {
+public:
+  ~Workers() {
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      quit = true;
+    }
+    go.notify_all();
+    for (std::thread &t : threads)
+      t.join();
+  }
+  // fn(first, last) over [0, n) in at most `max_blocks` blocks of at least `min_block` items
+  void run(size_t n, size_t min_block, const std::function<void(size_t, size_t)> &fn) {
+    size_t blocks = std::min<size_t>(n / std::max<size_t>(min_block, 1), kMaxThreads);
+    if (blocks < 2) {
+      fn(0, n);
+      return;
+    }
+    if (threads.empty()) {
+      size_t hw = std::thread::hardware_concurrency();
+      size_t helpers = std::min<size_t>(kMaxThreads, hw > 1 ? hw : 1) - 1;
+      for (size_t i = 0; i < helpers; ++i)
+        threads.emplace_back([this, i] { loop(i + 1); });
+    }
+    blocks = std::min(blocks, threads.size() + 1);
+    if (blocks < 2) {
+      fn(0, n);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      job = &fn;
+      job_n = n;
+      job_blocks = blocks;
+      pending = blocks - 1;
+      ++generation;
+    }
+    go.notify_all();
+    fn(0, n / blocks);
+    std::unique_lock<std::mutex> lock(mu);
+    done.wait(lock, [this] { return pending == 0; });
+    job = nullptr;
+  }
+
+private:
+  static constexpr size_t kMaxThreads = 16;
+  void loop(size_t index) {
+    size_t seen = 0;
+    for (;;) {
+      const std::function<void(size_t, size_t)> *fn = nullptr;
+      size_t n = 0, blocks = 0;
+      {
+        std::unique_lock<std::mutex> lock(mu);
+        go.wait(lock, [&] { return quit || generation != seen; });
+        if (quit)
+          return;
+        seen = generation;
+        if (index >= job_blocks)
+          continue; // this round needs fewer blocks than there are helpers
+        fn = job;
+        n = job_n;
+        blocks = job_blocks;
+      }
+      (*fn)(n * index / blocks, n * (index + 1) / blocks);
+      std::lock_guard<std::mutex> lock(mu);
+      if (--pending == 0)
+        done.notify_one();
+    }
+  }
+  std::vector<std::thread> threads;
+  std::mutex mu;
+  std::condition_variable go, done;
+  const std::function<void(size_t, size_t)> *job = nullptr;
+  size_t job_n = 0, job_blocks = 0, pending = 0, generation = 0;
+  bool quit = false;
+};
 
 struct lk_tracker {
   lk_tracker_config cfg{};
@@ -43,6 +129,12 @@ struct lk_tracker {
   bool report_enabled = true;
   std::string err;
   bool begun = false;
+  Workers workers;
+  // scratch of lk_sequence_frame (kept: three multi-megabyte buffers per frame otherwise)
+  std::vector<lk_sector_command> seq_cmds;
+  std::vector<float> seq_guesses;
+  std::vector<lk_result> seq_results;
+  std::vector<float> global_terms_scratch;
 
   int fail(int code, const char *what) {
     err = what;
@@ -212,27 +304,22 @@ static void report_rows(const lk_tracker *t, size_t first, size_t last, int fram
 static void add_frame_to_report(lk_tracker *t, int frame, const char *und, const char *def) {
   if (!t->report_enabled)
     return;
-  const size_t S = t->res.size();
-  const size_t kRowsPerThread = 2048;
-  size_t workers = std::min<size_t>(S / kRowsPerThread, std::min<size_t>(16, std::thread::hardware_concurrency()));
-  if (workers < 2)
-    workers = 1;
+  const size_t S = t->res.size(), kRowsPerBlock = 2048, kMaxBlocks = 16;
+  const size_t blocks = std::max<size_t>(1, std::min(S / kRowsPerBlock, kMaxBlocks));
   const size_t base = t->report_blocks.size();
-  t->report_blocks.resize(base + workers); // blocks are joined only when the text is asked for
+  t->report_blocks.resize(base + blocks); // blocks are joined only when the text is asked for
   std::string *part = &t->report_blocks[base];
-  auto work = [=](size_t w) {
-    const size_t first = S * w / workers, last = S * (w + 1) / workers;
-    std::string rows; // (a local: the block headers sit side by side in one cache line)
-    rows.reserve((last - first) * (size_t)(96 + 26 * t->P) + 64);
-    report_rows(t, first, last, frame, und, def, rows);
-    part[w] = std::move(rows);
-  };
-  std::vector<std::thread> th;
-  for (size_t w = 1; w < workers; ++w)
-    th.emplace_back(work, w);
-  work(0);
-  for (std::thread &x : th)
-    x.join();
+  // fixed row blocks (whatever the number of threads that format them): block b = rows
+  // [S*b/blocks, S*(b+1)/blocks)
+  t->workers.run(blocks, 1, [&](size_t b0, size_t b1) {
+    for (size_t b = b0; b < b1; ++b) {
+      const size_t first = S * b / blocks, last = S * (b + 1) / blocks;
+      std::string rows; // (a local: the block headers sit side by side in one cache line)
+      rows.reserve((last - first) * (size_t)(96 + 26 * t->P) + 64);
+      report_rows(t, first, last, frame, und, def, rows);
+      part[b] = std::move(rows);
+    }
+  });
 }
 
 // the Lagrangian branch shared by adjust_rectangular/annular/blob_domain
@@ -339,15 +426,19 @@ static void update_results(lk_tracker *t, lk_frame_result &s, const lk_result &r
   }
 }
 
-static void update_global_results(lk_tracker *t) { // :2709-2753
+// :2709-2753.  The weighted sums run over the sectors in order, in float, like the reference's
+// loop; `terms` ([S][5]: the products and n, filled by the update_results pass) keeps that
+// sequential part on a compact array instead of a second walk over the 200-byte records.
+static void update_global_results(lk_tracker *t, const std::vector<float> &terms) {
   float average_angle = 0.f, average_center_x = 0.f, average_center_y = 0.f, average_e = 0.f, total_n = 0.f;
-  for (const lk_frame_result &s : t->res) {
-    float n = (float)s.number_of_points;
-    average_angle += s.def_angle * n;
-    average_center_x += s.def_center_x * n;
-    average_center_y += s.def_center_y * n;
-    average_e += s.def_e * n;
-    total_n += n;
+  const size_t S = t->res.size();
+  for (size_t k = 0; k < S; ++k) {
+    const float *q = &terms[5 * k];
+    average_angle += q[0];
+    average_center_x += q[1];
+    average_center_y += q[2];
+    average_e += q[3];
+    total_n += q[4];
   }
   average_angle = average_angle / total_n;
   average_center_x = average_center_x / total_n;
@@ -355,14 +446,26 @@ static void update_global_results(lk_tracker *t) { // :2709-2753
   average_e = average_e / total_n;
   float und_ro = t->res[0].und_global_ro, und_ri = t->res[0].und_global_ri;
   float def_ri = 1.f + average_e * (und_ro / und_ri - 1.f);
-  for (lk_frame_result &s : t->res) {
-    s.def_global_angle = average_angle;
-    s.def_global_center_x = average_center_x;
-    s.def_global_center_y = average_center_y;
-    s.def_global_e = average_e;
-    s.def_global_ro = s.und_global_ro;
-    s.def_global_ri = def_ri;
-  }
+  t->workers.run(S, 4096, [&](size_t k0, size_t k1) {
+    for (size_t k = k0; k < k1; ++k) {
+      lk_frame_result &s = t->res[k];
+      s.def_global_angle = average_angle;
+      s.def_global_center_x = average_center_x;
+      s.def_global_center_y = average_center_y;
+      s.def_global_e = average_e;
+      s.def_global_ro = s.und_global_ro;
+      s.def_global_ri = def_ri;
+    }
+  });
+}
+
+static void global_terms(const lk_frame_result &s, float *q) {
+  const float n = (float)s.number_of_points;
+  q[0] = s.def_angle * n;
+  q[1] = s.def_center_x * n;
+  q[2] = s.def_center_y * n;
+  q[3] = s.def_e * n;
+  q[4] = n;
 }
 
 extern "C" {
@@ -458,7 +561,8 @@ int lk_tracker_begin_frame(lk_tracker *t, int frame, lk_sector_command *commands
     return LK_ERROR_BAD_DOMAIN;
   if (!t->domain_set || !commands || !guesses || frame < 0)
     return t->fail(LK_ERROR_BAD_DOMAIN, "lk_tracker_begin_frame: no domain / null buffers");
-  t->before = t->res;
+  if (t->cfg.error_mode != LK_ERRMODE_CONTINUE)
+    t->before = t->res; // what lk_tracker_end_frame gives back to sectors a stopped frame never reached
   const int S = (int)t->res.size();
   const bool eulerian = t->cfg.deformation == LK_DEF_EULERIAN;
   auto later_frames = [&](lk_frame_result &s, lk_sector_command &c) { // manager_class.cpp:354-419
@@ -478,9 +582,9 @@ int lk_tracker_begin_frame(lk_tracker *t, int frame, lk_sector_command *commands
     lkroi::RectGrid g = lkroi::rect_grid(t->x_begin, t->y_begin, t->x_end, t->y_end, t->hs, t->vs);
     if (g.xdim < 0 || g.ydim < 0)
       return t->fail(LK_ERROR_BAD_DOMAIN, "lk_tracker_begin_frame: domain smaller than the grid");
-    for (int i = 0; i < t->hs; ++i)
-      for (int j = 0; j < t->vs; ++j) {
-        const int k = i * t->vs + j;
+    t->workers.run((size_t)S, 4096, [&](size_t k0, size_t k1) {
+      for (size_t kk = k0; kk < k1; ++kk) {
+        const int k = (int)kk, i = k / t->vs, j = k % t->vs; // iSector = i*vs + j
         lk_frame_result &s = t->res[(size_t)k];
         lk_sector_command &c = commands[k];
         if (frame == 0) {
@@ -508,6 +612,7 @@ int lk_tracker_begin_frame(lk_tracker *t, int frame, lk_sector_command *commands
           later_frames(s, c);
         }
       }
+    });
     break;
   }
   case LK_DOMAIN_ANNULAR: { // manager_class.cpp:553-600 + adjust_annular_domain :2092-2237
@@ -592,21 +697,31 @@ int lk_tracker_end_frame(lk_tracker *t, int frame, const char *und_name, const c
     return t->fail(LK_ERROR_BAD_DOMAIN, "lk_tracker_end_frame: lk_tracker_begin_frame has not been called");
   const int S = (int)t->res.size();
   const bool stop_mode = t->cfg.error_mode != LK_ERRMODE_CONTINUE;
-  bool error = false;
-  int k = 0;
-  for (; k < S; ++k) { // the sector loop after the solve (manager_class.cpp:452-547)
-    update_results(t, t->res[(size_t)k], results[k]);
-    error = t->res[(size_t)k].error_status != 0; // `error` is overwritten by every sector
-    if (error && stop_mode) {
-      ++k;
-      break;
+  // the sector loop after the solve (manager_class.cpp:452-547): `error` is overwritten by
+  // every sector, and under stopAll / stopFrame the loop ends after the first failing one
+  int k = S;
+  if (stop_mode)
+    for (int u = 0; u < S; ++u)
+      if (results[u].errorCode != LK_ERROR_NONE) {
+        k = u + 1;
+        break;
+      }
+  std::vector<float> &terms = t->global_terms_scratch;
+  terms.resize(5 * (size_t)S);
+  t->workers.run((size_t)k, 4096, [&](size_t u0, size_t u1) {
+    for (size_t u = u0; u < u1; ++u) {
+      update_results(t, t->res[u], results[u]);
+      global_terms(t->res[u], &terms[5 * u]);
     }
-  }
-  for (int u = k; u < S; ++u) // not reached by the reference's loop: as before this frame
+  });
+  const bool error = k > 0 && t->res[(size_t)k - 1].error_status != 0;
+  for (int u = k; u < S; ++u) { // not reached by the reference's loop: as before this frame
     t->res[(size_t)u] = t->before[(size_t)u];
+    global_terms(t->res[(size_t)u], &terms[5 * (size_t)u]);
+  }
   if (first_unsolved)
     *first_unsolved = k;
-  update_global_results(t);
+  update_global_results(t, terms);
   add_frame_to_report(t, frame, und_name ? und_name : "", def_name ? def_name : "");
   if (stop_sequence) // manager_class.cpp:1485-1486
     *stop_sequence = error && t->cfg.error_mode == LK_ERRMODE_STOP_ALL;
@@ -652,8 +767,10 @@ int lk_sequence_frame(lk_engine *e, lk_tracker *t, int frame, const char *und_na
   if (!e || !t)
     return LK_ERROR_BAD_DOMAIN;
   const int S = lk_tracker_sector_count(t);
-  std::vector<lk_sector_command> cmds((size_t)S);
-  std::vector<float> guesses(6 * (size_t)S);
+  std::vector<lk_sector_command> &cmds = t->seq_cmds;
+  std::vector<float> &guesses = t->seq_guesses;
+  cmds.resize((size_t)S);
+  guesses.resize(6 * (size_t)S);
   int rc = lk_tracker_begin_frame(t, frame, cmds.data(), guesses.data());
   if (rc)
     return rc;
@@ -691,7 +808,8 @@ int lk_sequence_frame(lk_engine *e, lk_tracker *t, int frame, const char *und_na
   }
   if (rc)
     return rc;
-  std::vector<lk_result> results((size_t)S);
+  std::vector<lk_result> &results = t->seq_results;
+  results.resize((size_t)S);
   rc = lk_correlate_all(e, guesses.data(), results.data());
   if (rc)
     return rc;
