@@ -72,7 +72,7 @@ struct LkSolveArgs {
   int max_iters;
 };
 
-struct LkRewarpArgs { // level-0 sample lists moved by the last level-0 evaluation's parameters
+struct LkRewarpArgs { // level-0 sample lists moved by the last level-0 evaluation's parameters (or by an offset)
   const float2 *src_xy;    // lists before (explicit sectors)
   const uint32_t *src_off; // [S+1]
   const int4 *src_rect;    // [S] implicit rectangles before (width 0: explicit)
@@ -80,6 +80,7 @@ struct LkRewarpArgs { // level-0 sample lists moved by the last level-0 evaluati
   float2 *dst_xy;
   const float2 *center;    // [S] centres of the last solve
   const float *p;          // [S][6]
+  const float2 *offset;    // [S] Lagrangian description: samples move by add_pair(offset) instead of the warp
   int n_sectors;
   uint32_t total;          // dst_off[S]
 };

@@ -152,7 +152,8 @@ struct lk_engine {
   bool lists_on_device = false, backup_on_device = false;
   DevBuf<float2> d_xy0_alt;
   DevBuf<uint32_t> d_off0_alt, d_pos, d_tiles, d_level_total;
-  std::vector<float> h_center_prev;
+  std::vector<float> h_center_prev, h_offsets;
+  DevBuf<float2> d_offsets;
   int S = 0;
   std::vector<uint32_t> h_off[LK_MAX_LEVELS];
   DevBuf<float2> d_xy[LK_MAX_LEVELS];
@@ -263,6 +264,7 @@ void lk_destroy(lk_engine *e) {
   e->d_pos.release();
   e->d_tiles.release();
   e->d_level_total.release();
+  e->d_offsets.release();
   e->d_guess.release();
   e->d_last_p.release();
   e->d_last_eval_p.release();
@@ -978,11 +980,26 @@ static void rewarp_one(HostSector &h, int model, const float *p, const float *ce
   }
 }
 
+static int rewarp_on_device(lk_engine *e, const float *centers_xy, const float *offsets_xy = nullptr);
+
 int lk_translate_sectors(lk_engine *e, const float *offsets_xy, const float *centers_xy) {
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
   if (!e->committed || !offsets_xy)
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_translate_sectors: sectors are not committed");
+  {
+    // Explicit lists (annular / blob / point sectors) move on the device like the strict
+    // Lagrangian ones; implicit rectangles stay with the host records - a rectangle that moves
+    // by whole pixels stays implicit, which is O(sectors) work and keeps its faster sampling.
+    const char *f = std::getenv("LK_HOST_REWARP"); // test hook, read per call
+    bool device_path = !(f && std::atoi(f) != 0) && !e->recommit_pending;
+    for (int s = 0; s < e->S && device_path; ++s)
+      device_path = e->h_rect[0][(size_t)s].z == 0;
+    if (device_path) {
+      HIPCHK(hipSetDevice(e->cfg.device));
+      return rewarp_on_device(e, centers_xy, offsets_xy);
+    }
+  }
   {
     int rc = materialize_host(e);
     if (rc)
@@ -1006,7 +1023,7 @@ int lk_translate_sectors(lk_engine *e, const float *offsets_xy, const float *cen
 // applies the decimation rule to all sectors at once, a one-lane-per-sector kernel recomputes the
 // mean centres where the caller gives none; the host reads back only the per-level offsets
 // (starved-level bookkeeping).  LK_HOST_REWARP=1 keeps the host path (tests compare the two).
-static int rewarp_on_device(lk_engine *e, const float *centers_xy) {
+static int rewarp_on_device(lk_engine *e, const float *centers_xy, const float *offsets_xy) {
   const int S = e->S;
   const lk_config &cfg = e->cfg;
   hipStream_t st = e->stream;
@@ -1043,6 +1060,12 @@ static int rewarp_on_device(lk_engine *e, const float *centers_xy) {
   a.p = e->d_last_eval_p.p;
   a.n_sectors = S;
   a.total = total;
+  if (offsets_xy) { // Lagrangian description: the sectors' offsets instead of the warp
+    e->h_offsets.assign(offsets_xy, offsets_xy + 2 * (size_t)S);
+    HIPCHK(e->d_offsets.ensure((size_t)S));
+    HIPCHK(hipMemcpyAsync(e->d_offsets.p, e->h_offsets.data(), 2 * (size_t)S * sizeof(float), hipMemcpyHostToDevice, st));
+    a.offset = e->d_offsets.p;
+  }
   HIPCHK(lk_launch_rewarp(a, cfg.fitting_model, st));
   // what lk_restore_sectors needs: the previous lists stay in the alternate buffer when they
   // were device-built too, otherwise the host records are still good

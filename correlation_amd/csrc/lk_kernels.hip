@@ -2047,6 +2047,12 @@ __global__ void lk_warp_points_kernel(const float2 *xy, int n, float cx, float c
 // of the next frame; pyramid_class.cpp:289-323 then decimates them level by level.  Sectors are
 // concatenated in sector order, so ONE order-preserving compaction of the whole level is the
 // per-sector compaction of every sector at once.
+// (int)(v + 0.5f) as the host code computes it: out-of-range and NaN give INT_MIN (cvttss2si)
+__device__ __forceinline__ int round_like_host(float v) {
+  const float t = v + 0.5f;
+  return fabsf(t) < 2147483648.f ? (int)t : (int)0x80000000;
+}
+
 template <int MODEL> __global__ void lk_rewarp_kernel(LkRewarpArgs a) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.total)
@@ -2070,6 +2076,11 @@ template <int MODEL> __global__ void lk_rewarp_kernel(LkRewarpArgs a) {
   } else {
     q = a.src_xy[a.src_off[s] + k];
   }
+  if (a.offset) { // Lagrangian description: add_pair(offset), manager_class.cpp:38-47
+    const float2 o = a.offset[s];
+    a.dst_xy[i] = make_float2((float)round_like_host(o.x + q.x), (float)round_like_host(o.y + q.y));
+    return;
+  }
   float p[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j)
@@ -2080,11 +2091,6 @@ template <int MODEL> __global__ void lk_rewarp_kernel(LkRewarpArgs a) {
   a.dst_xy[i] = make_float2(xd, yd);
 }
 
-// (int)(v + 0.5f) as the host code computes it: out-of-range and NaN give INT_MIN (cvttss2si)
-__device__ __forceinline__ int round_like_host(float v) {
-  const float t = v + 0.5f;
-  return fabsf(t) < 2147483648.f ? (int)t : (int)0x80000000;
-}
 __device__ __forceinline__ bool decimate_keeps(float2 q, int mag) {
   return round_like_host(q.x) % mag == 0 && round_like_host(q.y) % mag == 0;
 }
@@ -2183,20 +2189,40 @@ __global__ void lk_decimate_offsets_kernel(const uint32_t *off_prev, const uint3
 }
 
 // Newton_Raphson(p, n, xy) solves about the float mean of the samples, summed in list order
-// (pyramid_class.cpp:325-340): one lane per sector, sequential
-__global__ void lk_mean_center_kernel(const float2 *xy, const uint32_t *off, int n_sectors, float2 *center) {
-  const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+// (pyramid_class.cpp:325-340).  The order is the reference's, so the additions are one chain
+// per coordinate; what is parallel is the memory side: a wavefront per sector fetches 64
+// consecutive samples with one coalesced load and feeds them to the chain lane by lane
+// (v_readlane), instead of one lane waiting for one cache line per sample.
+__global__ void __launch_bounds__(kWave) lk_mean_center_kernel(const float2 *xy, const uint32_t *off, int n_sectors,
+                                                                float2 *center) {
+  const int s = (int)blockIdx.x;
   if (s >= n_sectors)
     return;
   const uint32_t b = off[s], e = off[s + 1];
+  const int lane = (int)threadIdx.x;
   float sx = 0.f, sy = 0.f;
-  for (uint32_t i = b; i < e; ++i) {
-    const float2 q = xy[i];
-    sx += q.x;
-    sy += q.y;
+  for (uint32_t base = b; base < e; base += kWave) {
+    const uint32_t i = base + (uint32_t)lane;
+    const float2 q = i < e ? xy[i] : make_float2(0.f, 0.f);
+    const int qx = __float_as_int(q.x), qy = __float_as_int(q.y);
+    if (e - base >= (uint32_t)kWave) {
+#pragma unroll
+      for (int l = 0; l < kWave; ++l) {
+        sx += __int_as_float(__builtin_amdgcn_readlane(qx, l));
+        sy += __int_as_float(__builtin_amdgcn_readlane(qy, l));
+      }
+    } else {
+      const int n = (int)(e - base);
+      for (int l = 0; l < n; ++l) {
+        sx += __int_as_float(__builtin_amdgcn_readlane(qx, l));
+        sy += __int_as_float(__builtin_amdgcn_readlane(qy, l));
+      }
+    }
   }
-  const float n = (float)(e - b);
-  center[s] = make_float2(__fdiv_rn(sx, n), __fdiv_rn(sy, n));
+  if (lane == 0) {
+    const float n = (float)(e - b);
+    center[s] = make_float2(__fdiv_rn(sx, n), __fdiv_rn(sy, n));
+  }
 }
 
 } // namespace
@@ -2480,7 +2506,6 @@ hipError_t lk_launch_decimate(const float2 *xy_prev, const uint32_t *off_prev, c
 hipError_t lk_launch_mean_center(const float2 *xy, const uint32_t *off, int n_sectors, float2 *center, hipStream_t st) {
   if (n_sectors <= 0)
     return hipSuccess;
-  hipLaunchKernelGGL(lk_mean_center_kernel, dim3((unsigned)(n_sectors + 63) / 64), dim3(64), 0, st, xy, off, n_sectors,
-                     center);
+  hipLaunchKernelGGL(lk_mean_center_kernel, dim3((unsigned)n_sectors), dim3(kWave), 0, st, xy, off, n_sectors, center);
   return hipGetLastError();
 }

@@ -188,8 +188,9 @@ int lk_commit_sectors(lk_engine *e);
  *    parameters of the last level-0 evaluation) become the undeformed samples.
  * offsets_xy [S][2]; centers_xy [S][2] = centres for the next solve (the rectangular path
  * passes integers, manager_class.cpp:438-441) or NULL = float mean of the new samples.
- * lk_rewarp_sectors rebuilds the lists of every pyramid level on the device (the samples never
- * visit the host); lk_translate_sectors works on the host records (rectangles stay implicit). */
+ * Both rebuild the lists of every pyramid level on the device (the samples never visit the
+ * host), except that lk_translate_sectors keeps grids of implicit rectangles on the host
+ * records: a rectangle that moves by whole pixels stays implicit. */
 int lk_translate_sectors(lk_engine *e, const float *offsets_xy, const float *centers_xy);
 int lk_rewarp_sectors(lk_engine *e, const float *centers_xy);
 /* one sector, from the engine's own last record of it - the call shape of

@@ -840,14 +840,19 @@ def test_sequence_tracking_against_manager_oracle(oracle, domain, deformation, r
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("given_centers,model,py_stop", [(True, ca.FM_UVUXUYVXVY, 2), (False, ca.FM_UVQ, 2),
-                                                         (False, ca.FM_UV, 3), (True, ca.FM_U, 1)])
-def test_device_rebuilt_lists_equal_the_host_rebuild(monkeypatch, given_centers, model, py_stop):
+@pytest.mark.parametrize("given_centers,model,py_stop,move", [
+    (True, ca.FM_UVUXUYVXVY, 2, "rewarp"), (False, ca.FM_UVQ, 2, "rewarp"), (False, ca.FM_UV, 3, "rewarp"),
+    (True, ca.FM_U, 1, "rewarp"), (False, ca.FM_UVUXUYVXVY, 2, "translate"), (True, ca.FM_UVQ, 3, "translate")])
+def test_device_rebuilt_lists_equal_the_host_rebuild(monkeypatch, given_centers, model, py_stop, move):
     """lk_rewarp_sectors rebuilds the moved sample lists on the device (warp, per-level
     decimation as one compaction, mean centres); the host rebuild (LK_HOST_REWARP=1) is the
     restated reference loop.  Lists, centres, per-level counts and the next solve's records must
     be the same bits - over two moves and a partial restore."""
     frames = ca.speckle.speckle_sequence(320, 288, 3, velocity=(0.7, -0.4), dilation=6e-4, seed=9)
+
+    def oracle_free_rect(x0, y0, x1, y1):   # the samples of a rectangle as an explicit list, x outer / y inner
+        xs, ys = np.meshgrid(np.arange(x0, x1 + 1), np.arange(y0, y1 + 1), indexing="ij")
+        return np.stack([xs.ravel(), ys.ravel()], 1).astype(np.float32)
 
     def run(host):
         monkeypatch.setenv("LK_HOST_REWARP", "1" if host else "0")
@@ -856,14 +861,22 @@ def test_device_rebuilt_lists_equal_the_host_rebuild(monkeypatch, given_centers,
         e.set_batch_invariant(True)
         e.set_undeformed_image(frames[0])
         e.set_deformed_image(frames[1])
-        e.resetPolygon_rect(0, 40, 50, 70, 75)
+        if move == "translate":     # explicit lists only: implicit rectangles stay with the host records
+            e.set_sector_points(0, oracle_free_rect(40, 50, 70, 75), center=(55.0, 62.5))
+        else:
+            e.resetPolygon_rect(0, 40, 50, 70, 75)
         e.resetPolygon_annular(1, 40.0, 30.0, 0.3, 1.1, 150.0, 140.0, 1)
         ang = 2 * np.pi * np.arange(9) / 9
         e.resetPolygon_blob(2, np.stack([200 + 50 * np.cos(ang), 90 + 40 * np.sin(ang)], 1).astype(np.float32))
-        e.resetPolygon_rect(3, 100, 200, 104, 203)          # 5 x 4 samples: starved upper levels
         pts = np.stack([rng.uniform(60, 250, 700), rng.uniform(60, 220, 700)], 1).astype(np.float32)
-        e.set_sector_points(4, pts, center=(155.25, 140.5))
-        e.resetPolygon_rect(5, 180, 160, 260, 250)
+        if move == "translate":
+            e.set_sector_points(3, oracle_free_rect(100, 200, 104, 203), center=(102.0, 201.5))
+            e.set_sector_points(4, np.round(pts), center=(155.25, 140.5))
+            e.set_sector_points(5, oracle_free_rect(180, 160, 260, 250), center=(220.0, 205.0))
+        else:
+            e.resetPolygon_rect(3, 100, 200, 104, 203)          # 5 x 4 samples: starved upper levels
+            e.set_sector_points(4, pts, center=(155.25, 140.5))
+            e.resetPolygon_rect(5, 180, 160, 260, 250)
         e.commit_sectors()
         S = e.n_sectors
         out = []
@@ -874,7 +887,10 @@ def test_device_rebuilt_lists_equal_the_host_rebuild(monkeypatch, given_centers,
             # (no host-side query here: the second move must find the first one's lists on the device)
             centers = np.stack([np.trunc(r["und_cx"] + r["p"][:, 0] + 0.5), np.trunc(r["und_cy"] + 0.5)],
                                1).astype(np.float32) if given_centers else None
-            e.rewarp_sectors(centers)
+            if move == "translate":
+                e.translate_sectors(np.ascontiguousarray(r["p"][:, :2] + np.float32([0.3, 0.0])), centers)
+            else:
+                e.rewarp_sectors(centers)
             counts = [[e.sector_level_count(s, l) for l in range(py_stop + 1)] for s in range(S)]
             if k == 0:      # the lists stay on the device between the frames of a sequence
                 e.makeUndPyramidFromDef()
