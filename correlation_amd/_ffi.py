@@ -72,6 +72,7 @@ SYMBOLS = {
                                    C.c_int, C.c_int, C.c_int]),
     "lk_set_sector_annular": (C.c_int, [_P, C.c_int, C.c_float, C.c_float, C.c_float,
                                         C.c_float, C.c_float, C.c_float, C.c_int]),
+    "lk_set_sectors_annular": (C.c_int, [_P, C.c_int, C.c_int, _F, C.c_int]),
     "lk_set_sector_blob": (C.c_int, [_P, C.c_int, _F, C.c_int]),
     "lk_set_sector_points": (C.c_int, [_P, C.c_int, _F, C.c_int, C.c_int, C.c_float, C.c_float]),
     "lk_commit_sectors": (C.c_int, [_P]),

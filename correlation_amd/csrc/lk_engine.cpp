@@ -21,6 +21,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 hipError_t lk_launch_solve(const LkSolveArgs &a, int model, int interp, int group, hipStream_t st);
@@ -661,6 +662,43 @@ int lk_set_sector_annular(lk_engine *e, int sector, float r, float dr, float a, 
   return LK_ERROR_NONE;
 }
 
+int lk_set_sectors_annular(lk_engine *e, int first_sector, int count, const float *params, int as) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (first_sector < 0 || count < 1 || !params)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sectors_annular: bad arguments");
+  if (!sector_slot(e, first_sector + count - 1)) // sizes the table once, before the threads
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sectors_annular: bad sector range");
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int workers = std::max(1, std::min({count, 16, (int)(hw ? hw : 1)}));
+  std::vector<int> empty((size_t)workers, 0);
+  auto work = [&](int w) {
+    for (int k = w; k < count; k += workers) { // interleaved: neighbouring rings have similar sizes
+      const float *q = params + 6 * (size_t)k;
+      HostSector &s = e->hs[(size_t)(first_sector + k)];
+      s.xy.clear();
+      s.is_rect = false;
+      if (!lkroi::annular_points(q[0], q[1], q[2], q[3], q[4], q[5], as, s.xy) || s.xy.empty()) {
+        empty[(size_t)w] = 1;
+        continue;
+      }
+      lkroi::mean_center(s.xy.data(), (int)(s.xy.size() / 2), s.cx, s.cy); // correlation_class.cpp:337-339
+      s.has_center = false;
+      s.set = true;
+    }
+  };
+  std::vector<std::thread> th;
+  for (int w = 1; w < workers; ++w)
+    th.emplace_back(work, w);
+  work(0);
+  for (std::thread &t : th)
+    t.join();
+  for (int v : empty)
+    if (v)
+      return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sectors_annular: empty sector");
+  return LK_ERROR_NONE;
+}
+
 int lk_set_sector_blob(lk_engine *e, int sector, const float *contour_xy, int n_vertices) {
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
@@ -754,6 +792,11 @@ static int commit_impl(lk_engine *e, bool keep_state) {
   e->h_center.resize(2 * (size_t)S);
   for (int l : levels)
     e->h_rect[l].assign((size_t)S, make_int4(0, 0, 0, 0));
+  // Long explicit lists (annular / blob domains) are decimated on the device: one order-
+  // preserving compaction per coarser level over all sectors at once (the kernels of
+  // lk_rewarp_sectors); LK_HOST_REWARP=1 keeps the restated reference loop (tests compare).
+  const char *host_env = std::getenv("LK_HOST_REWARP");
+  const bool device_levels = !(host_env && std::atoi(host_env) != 0) && total0 / 2 >= 32768 && levels.size() > 1;
   std::vector<float> prev, cur;
   for (int s = 0; s < S; ++s) {
     const HostSector &hs = e->hs[(size_t)s];
@@ -773,6 +816,8 @@ static int commit_impl(lk_engine *e, bool keep_state) {
     }
     cat[0].insert(cat[0].end(), hs.xy.begin(), hs.xy.end());
     e->h_off[0].push_back((uint32_t)(cat[0].size() / 2));
+    if (device_levels)
+      continue;
     const float *pxy = hs.xy.data();
     int pn = (int)(hs.xy.size() / 2), plevel = 0;
     for (size_t li = 1; li < levels.size(); ++li) {
@@ -788,14 +833,33 @@ static int commit_impl(lk_engine *e, bool keep_state) {
     }
   }
   for (int l : levels) {
-    HIPCHK(e->d_xy[l].ensure(cat[l].size() / 2 + 1));
+    const bool on_device = device_levels && l > 0;
+    HIPCHK(e->d_xy[l].ensure((on_device ? cat[0].size() : cat[l].size()) / 2 + 1));
     HIPCHK(e->d_off[l].ensure((size_t)S + 1));
-    if (!cat[l].empty())
-      HIPCHK(hipMemcpy(e->d_xy[l].p, cat[l].data(), cat[l].size() * sizeof(float), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d_off[l].p, e->h_off[l].data(), ((size_t)S + 1) * sizeof(uint32_t),
-                     hipMemcpyHostToDevice));
+    if (!on_device) {
+      if (!cat[l].empty())
+        HIPCHK(hipMemcpy(e->d_xy[l].p, cat[l].data(), cat[l].size() * sizeof(float), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(e->d_off[l].p, e->h_off[l].data(), ((size_t)S + 1) * sizeof(uint32_t),
+                       hipMemcpyHostToDevice));
+    }
     HIPCHK(e->d_rect[l].ensure((size_t)S));
     HIPCHK(hipMemcpy(e->d_rect[l].p, e->h_rect[l].data(), (size_t)S * sizeof(int4), hipMemcpyHostToDevice));
+  }
+  if (device_levels) {
+    const uint32_t total = (uint32_t)(cat[0].size() / 2);
+    HIPCHK(e->d_level_total.ensure(LK_MAX_LEVELS));
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)e->d_level_total.p, (int)total, 1, e->stream));
+    HIPCHK(e->d_pos.ensure((size_t)total + 1));
+    HIPCHK(e->d_tiles.ensure((size_t)lk_decimate_tiles(total) + 2));
+    for (size_t li = 1; li < levels.size(); ++li) {
+      const int l = levels[li], pl = levels[li - 1];
+      HIPCHK(lk_launch_decimate(e->d_xy[pl].p, e->d_off[pl].p, e->d_level_total.p + pl, total, l - pl, S, e->d_pos.p,
+                                e->d_tiles.p, e->d_xy[l].p, e->d_off[l].p, e->d_level_total.p + l, e->stream));
+      e->h_off[l].resize((size_t)S + 1);
+      HIPCHK(hipMemcpyAsync(e->h_off[l].data(), e->d_off[l].p, ((size_t)S + 1) * sizeof(uint32_t),
+                            hipMemcpyDeviceToHost, e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
   }
   HIPCHK(e->d_center.ensure((size_t)S));
   HIPCHK(hipMemcpy(e->d_center.p, e->h_center.data(), 2 * (size_t)S * sizeof(float), hipMemcpyHostToDevice));

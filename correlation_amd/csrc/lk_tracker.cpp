@@ -776,7 +776,19 @@ int lk_sequence_frame(lk_engine *e, lk_tracker *t, int frame, const char *und_na
     return rc;
   if (frame == 0) {
     rc = lk_clear_sectors(e);
-    for (int s = 0; s < S && !rc; ++s) {
+    bool annular = S > 0;
+    for (int s = 0; s < S && annular; ++s)
+      annular = cmds[(size_t)s].kind == LK_SECTOR_ANNULAR && cmds[(size_t)s].as == cmds[0].as;
+    if (annular && !rc) { // every sector of the annulus in one call: rasterised on several host threads
+      std::vector<float> q(6 * (size_t)S);
+      for (int s = 0; s < S; ++s) {
+        const lk_sector_command &c = cmds[(size_t)s];
+        const float v[6] = {c.r, c.dr, c.a, c.da, c.cx, c.cy};
+        std::memcpy(&q[6 * (size_t)s], v, sizeof(v));
+      }
+      rc = lk_set_sectors_annular(e, 0, S, q.data(), cmds[0].as);
+    }
+    for (int s = 0; s < S && !rc && !annular; ++s) {
       const lk_sector_command &c = cmds[(size_t)s];
       switch (c.kind) {
       case LK_SECTOR_RECT: rc = lk_set_sector_rect(e, s, c.x0, c.y0, c.x1, c.y1); break;

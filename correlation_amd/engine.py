@@ -132,6 +132,11 @@ class HipCorrelationEngine:
     def resetPolygon_annular(self, sector, r, dr, a, da, cx, cy, as_):
         self._chk(self.lib.lk_set_sector_annular(self._h, sector, r, dr, a, da, cx, cy, as_))
 
+    def set_sectors_annular(self, first_sector, params, as_):
+        """lk_set_sectors_annular: params [count][6] = (r, dr, a, da, cx, cy) per sector."""
+        q = np.ascontiguousarray(params, np.float32).reshape(-1, 6)
+        self._chk(self.lib.lk_set_sectors_annular(self._h, int(first_sector), len(q), _ffi.fptr(q), int(as_)))
+
     def resetPolygon_blob(self, sector, contour_xy):
         c = np.ascontiguousarray(contour_xy, dtype=np.float32).reshape(-1, 2)
         self._chk(self.lib.lk_set_sector_blob(self._h, sector, _ffi.fptr(c), c.shape[0]))

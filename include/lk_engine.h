@@ -167,6 +167,11 @@ int lk_set_rect_grid(lk_engine *e, float x_begin, float y_begin, float x_end, fl
  * CPU path's predicate and order (manager_class.cpp:816-940); centre = float mean */
 int lk_set_sector_annular(lk_engine *e, int sector, float r, float dr, float a, float da,
                           float cx, float cy, int as);
+/* the sectors first_sector .. first_sector+count-1 of an annular domain in one call - the sector
+ * loop of perform_single_frame_correlation_annular (manager_class.cpp:600-720) - rasterised by a
+ * few host threads, one sector each at a time (every list is the sequential scan's).
+ * params [count][6] = {r, dr, a, da, cx, cy} per sector. */
+int lk_set_sectors_annular(lk_engine *e, int first_sector, int count, const float *params, int as);
 /* CudaClass::resetPolygon(v_points) (cuda_class.cu:596-605) with polygonBlob_class
  * semantics (polygon_class.cpp:224-429); LK_ERROR_BAD_DOMAIN on a self-intersecting
  * contour (manager_class.cpp:1028-1031) */

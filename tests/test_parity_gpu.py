@@ -203,6 +203,42 @@ def test_pyramid_from_device_frames_bit_exact(oracle):
         e.close()
 
 
+def test_annulus_in_one_call_and_device_built_levels(monkeypatch, speckle512):
+    """lk_set_sectors_annular (all sectors of an annulus, rasterised on several host threads) and
+    the device-side decimation of long explicit lists at commit must give exactly what the
+    per-sector calls and the host decimation loop give: lists, centres, per-level counts, records."""
+    und, dfm = speckle512
+    rs, as_ = 3, 8
+    dr, da = (200.0 - 60.0) / rs, 2 * np.pi / as_
+    params = np.float32([[60.0 + i * dr, dr, j * da, da, 256.0, 250.0] for i in range(rs) for j in range(as_)])
+
+    def build(batch, host_levels):
+        monkeypatch.setenv("LK_HOST_REWARP", "1" if host_levels else "0")
+        e = ca.HipCorrelationEngine(py_stop=3)
+        e.set_batch_invariant(True)
+        e.set_undeformed_image(und)
+        e.set_deformed_image(dfm)
+        if batch:
+            e.set_sectors_annular(0, params, as_)
+        else:
+            for s, q in enumerate(params):
+                e.resetPolygon_annular(s, *[float(v) for v in q], as_)
+        e.commit_sectors()
+        S = e.n_sectors
+        out = ([e.getUndXY0ToCPU(s).tobytes() for s in range(S)], [e.sector_info(s) for s in range(S)],
+               [[e.sector_level_count(s, l) for l in range(4)] for s in range(S)], e.correlate_all().tobytes())
+        total = sum(i[0] for i in out[1])
+        e.close()
+        return out, total
+
+    want, total = build(False, True)
+    assert total >= 32768, total        # long enough for the device path
+    for batch, host_levels in ((True, True), (False, False), (True, False)):
+        got, _ = build(batch, host_levels)
+        for i, (w, g) in enumerate(zip(want, got)):
+            assert w == g, (batch, host_levels, i)
+
+
 def test_pairs_in_flight_give_the_records_of_a_lone_solve(speckle512):
     """Independent pairs solved side by side - one engine per pair, each on its own stream, all
     launches queued before any has finished (bench.py --inflight) - must give every pair the
