@@ -67,6 +67,7 @@ struct LkSolveArgs {
   int solo;              // 1: an idle half-wavefront may join its partner's sector (32-lane groups)
   int safe;              // 1: reference-exact handling of starved / ill-conditioned levels
   int persistent;        // 1: groups pull sectors from `queue`; 0: one sector per group by position
+  int gpu_share;         // launches that may hold the GPU at the same time (>= 1): bounds a team launch's width
   int py_start, py_step, py_stop;
   float precision;
   int max_iters;

@@ -132,6 +132,10 @@ struct lk_engine {
   int P = 0;
   hipStream_t own_stream = nullptr, stream = nullptr, nxt_stream = nullptr;
   hipEvent_t nxt_done = nullptr, ev_s0 = nullptr, ev_s1 = nullptr, ev_p0 = nullptr, ev_p1 = nullptr;
+  // size classes are independent sector sets: every class after the first solves on its own
+  // stream (forked from / joined into `stream`), so that one class's tail overlaps the others
+  hipStream_t class_stream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool nxt_pending = false, solve_timed = false, pyr_timed = false;
   bool batch_invariant = false; // lk_set_batch_invariant
   int pairs_in_flight = 1;      // lk_set_pairs_in_flight: launches that share the GPU
@@ -285,6 +289,14 @@ void lk_destroy(lk_engine *e) {
   e->d_warp.release();
   e->d_team_partials.release();
   e->d_team_arrivals.release();
+  for (hipStream_t cs : e->class_stream)
+    if (cs)
+      (void)hipStreamDestroy(cs);
+  for (hipEvent_t ev : e->ev_join)
+    if (ev)
+      (void)hipEventDestroy(ev);
+  if (e->ev_fork)
+    (void)hipEventDestroy(e->ev_fork);
   if (e->own_stream)
     (void)hipStreamDestroy(e->own_stream);
   if (e->nxt_stream)
@@ -756,7 +768,7 @@ static int refresh_starved(lk_engine *e) {
   }
   if (any_starved) {
     HIPCHK(e->d_finish_list.ensure((size_t)S));
-    HIPCHK(e->d_finish_count.ensure(1));
+    HIPCHK(e->d_finish_count.ensure(kNumClasses));
   }
   return LK_ERROR_NONE;
 }
@@ -968,8 +980,8 @@ static int commit_impl(lk_engine *e, bool keep_state) {
   HIPCHK(e->d_handoff.ensure((size_t)S));
   HIPCHK(e->d_mid.ensure((size_t)S * kLkMidWords));
   HIPCHK(e->d_ill_list.ensure((size_t)S));
-  HIPCHK(e->d_ill_count.ensure(1));
-  HIPCHK(hipMemset(e->d_ill_count.p, 0, sizeof(uint32_t)));
+  HIPCHK(e->d_ill_count.ensure(kNumClasses)); // one list region and one counter per class: classes solve concurrently
+  HIPCHK(hipMemset(e->d_ill_count.p, 0, kNumClasses * sizeof(uint32_t)));
   if (const char *f = std::getenv("LK_EVAL_CAP")) // tuning / test hook
     e->eval_cap = std::atoi(f);
   HIPCHK(e->d_scratch.ensure(64));
@@ -1410,6 +1422,7 @@ static LkSolveArgs base_args(lk_engine *e, const float *d_guess, lk_result *d_re
   a.precision = e->cfg.precision;
   a.max_iters = e->cfg.max_iters;
   a.solo = e->batch_invariant ? 0 : 1;
+  a.gpu_share = e->pairs_in_flight;
   static const int align = [] { // tuning hook; alignment never changes a record's bits
     const char *f = std::getenv("LK_ALIGN");
     return f ? std::atoi(f) : 1;
@@ -1421,21 +1434,23 @@ static LkSolveArgs base_args(lk_engine *e, const float *d_guess, lk_result *d_re
 // Starved levels: the one-lane-per-sector kernel (bit-identical sums and QR), whose lanes park
 // a sector after eval_cap evaluations, then the 16-lane finisher for the parked ones.  Both
 // leave an LkHandoff record per sector for the lane-group kernel that follows.
-static int launch_starved(lk_engine *e, LkSolveArgs &a) {
+// `c` picks the class's own region of the parked-sector lists and its own counters (classes
+// solve concurrently), `first` is where the class starts in d_order, `st` its stream.
+static int launch_starved(lk_engine *e, LkSolveArgs &a, int c, int first, hipStream_t st) {
   a.handoff = e->d_handoff.p;
   a.eval_cap = e->eval_cap > 0 ? e->eval_cap : 0;
   a.mid_state = e->d_mid.p;
-  a.finish_list = e->d_finish_list.p;
-  a.finish_count = e->d_finish_count.p;
+  a.finish_list = e->d_finish_list.p + first;
+  a.finish_count = e->d_finish_count.p + c;
   if (a.eval_cap > 0)
-    HIPCHK(hipMemsetAsync(e->d_finish_count.p, 0, sizeof(uint32_t), e->stream));
-  HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, 1, e->stream));
+    HIPCHK(hipMemsetAsync(a.finish_count, 0, sizeof(uint32_t), st));
+  HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, 1, st));
   if (a.eval_cap > 0) {
     LkSolveArgs f = a;
     f.finisher = 1;
     f.safe = 1;
     f.align = 0; // one trip per evaluation whatever the level: rows take the next parked sector as they finish
-    HIPCHK(lk_launch_solve(f, e->cfg.fitting_model, e->cfg.interpolation, 16, e->stream));
+    HIPCHK(lk_launch_solve(f, e->cfg.fitting_model, e->cfg.interpolation, 16, st));
   }
   a.eval_cap = 0;
   return LK_ERROR_NONE;
@@ -1444,27 +1459,27 @@ static int launch_starved(lk_engine *e, LkSolveArgs &a) {
 // The lane-group kernel of one class, then the SAFE 16-lane kernel for the sectors it parked
 // because a damped system met a bad pivot (the reference's rank-revealing QR decides those
 // steps; on textured images the list is empty and the second launch retires at once).
-static int launch_groups(lk_engine *e, LkSolveArgs &a, int group) {
+static int launch_groups(lk_engine *e, LkSolveArgs &a, int group, int c, int first, hipStream_t st) {
   static const bool ill_env = [] { const char *f = std::getenv("LK_ILL_PASS"); return f ? std::atoi(f) != 0 : true; }();
   const bool with_ill_pass = !a.safe && ill_env;
   if (with_ill_pass) {
     a.mid_state = e->d_mid.p;
-    a.ill_list = e->d_ill_list.p;
-    a.ill_count = e->d_ill_count.p; // (rewound by the SAFE pass itself)
+    a.ill_list = e->d_ill_list.p + first;
+    a.ill_count = e->d_ill_count.p + c; // (rewound by the SAFE pass itself)
   }
-  HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, group, e->stream));
+  HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, group, st));
   if (with_ill_pass) {
     LkSolveArgs r = a;
     r.resume = 1;
     r.safe = 1;
     r.ill_list = nullptr;
     r.ill_count = nullptr;
-    r.finish_list = e->d_ill_list.p;
-    r.finish_count = e->d_ill_count.p;
+    r.finish_list = a.ill_list;
+    r.finish_count = a.ill_count;
     r.team_w = 0;
     r.handoff = nullptr;
     r.queue = a.queue + 3;
-    HIPCHK(lk_launch_solve(r, e->cfg.fitting_model, e->cfg.interpolation, 16, e->stream));
+    HIPCHK(lk_launch_solve(r, e->cfg.fitting_model, e->cfg.interpolation, 16, st));
   }
   return LK_ERROR_NONE;
 }
@@ -1472,10 +1487,32 @@ static int launch_groups(lk_engine *e, LkSolveArgs &a, int group) {
 static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
   if (e->timing)
     HIPCHK(hipEventRecord(e->ev_s0, e->stream));
+  // Size classes are independent sector sets (own lists, counters and queue words): the first
+  // one solves on the engine's stream, every further one on a stream of its own forked from it
+  // and joined back, so that the tail of one class overlaps the others (config 3: 256 annular
+  // sectors + the blob's team).
+  static const bool overlap = [] { const char *f = std::getenv("LK_CLASS_STREAMS"); return f ? std::atoi(f) != 0 : true; }();
+  int n_classes = 0, n_launched = 0;
+  for (int c = 0; c < kNumClasses; ++c)
+    n_classes += e->class_begin[c + 1] > e->class_begin[c];
+  if (n_classes > 1 && overlap) { // guesses, views and images are ready at this point of the engine's stream
+    if (!e->ev_fork)
+      HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(e->ev_fork, e->stream));
+  }
   for (int c = 0; c < kNumClasses; ++c) {
     int n = e->class_begin[c + 1] - e->class_begin[c];
     if (n <= 0)
       continue;
+    hipStream_t st = e->stream;
+    if (n_launched > 0 && overlap) {
+      if (!e->class_stream[c]) {
+        HIPCHK(hipStreamCreateWithFlags(&e->class_stream[c], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&e->ev_join[c], hipEventDisableTiming));
+      }
+      st = e->class_stream[c];
+      HIPCHK(hipStreamWaitEvent(st, e->ev_fork, 0));
+    }
     LkSolveArgs a = base_args(e, d_guess, d_result);
     a.order = e->d_order.p + e->class_begin[c];
     a.n_sectors = n;
@@ -1488,15 +1525,20 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
       a.team_arrivals = e->d_team_arrivals.p;
     }
     if (e->class_starved[c]) { // coarsest level(s) first, one lane per sector (+ finisher)
-      int rc = launch_starved(e, a);
+      int rc = launch_starved(e, a, c, e->class_begin[c], st);
       if (rc)
         return rc;
     }
     {
-      int rc = launch_groups(e, a, kGroupOfClass[c]);
+      int rc = launch_groups(e, a, kGroupOfClass[c], c, e->class_begin[c], st);
       if (rc)
         return rc;
     }
+    if (st != e->stream) {
+      HIPCHK(hipEventRecord(e->ev_join[c], st));
+      HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join[c], 0));
+    }
+    ++n_launched;
   }
   if (e->timing) {
     HIPCHK(hipEventRecord(e->ev_s1, e->stream));
@@ -1572,12 +1614,12 @@ int lk_correlate(lk_engine *e, int sector, float *guess_inout, lk_result *out) {
   if (e->timing)
     HIPCHK(hipEventRecord(e->ev_s0, e->stream));
   if (e->class_starved[e->h_class[(size_t)sector]]) {
-    int rc = launch_starved(e, a);
+    int rc = launch_starved(e, a, 0, 0, e->stream);
     if (rc)
       return rc;
   }
   {
-    int rc = launch_groups(e, a, group);
+    int rc = launch_groups(e, a, group, 0, 0, e->stream);
     if (rc)
       return rc;
   }

@@ -2279,8 +2279,10 @@ static hipError_t launch_solve_gs(const LkSolveArgs &a, hipStream_t st) {
     return hipGetLastError();
   }
   if (GROUP == 512 && a.team_w > 1) {
-    // teams wait on each other: every workgroup of the launch must be resident at once
-    b.team_w = a.team_w < resident / a.n_sectors ? a.team_w : resident / a.n_sectors;
+    // teams wait on each other: every workgroup of the launch must be resident at once - also
+    // when other engines' team launches hold their share of the GPU (lk_set_pairs_in_flight)
+    const int share = resident / (a.gpu_share > 1 ? a.gpu_share : 1);
+    b.team_w = a.team_w < share / a.n_sectors ? a.team_w : share / a.n_sectors;
     if (b.team_w > 1) {
       hipError_t te = hipMemsetAsync(a.team_arrivals, 0, (size_t)a.n_sectors * sizeof(uint32_t), st);
       if (te != hipSuccess)

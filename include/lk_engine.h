@@ -124,7 +124,9 @@ int lk_set_batch_invariant(lk_engine *e, int enabled);
  * the GPU idle; the next pair's solve fills it (C2: 0.26 ms per pair one at a time, 0.15 ms
  * with three in flight).  n tells the engine how many launches share the GPU so that it keeps
  * the narrow, better-packed lane groups it would otherwise widen to shorten a lone solve
- * (default 1).  Call it before lk_commit_sectors.  Tracked sequences cannot use this: the
+ * (default 1), and it bounds the width of the multi-workgroup teams that solve giant sectors:
+ * team workgroups wait for each other, so engines whose team launches can be on the GPU at the
+ * same time MUST declare it.  Call it before lk_commit_sectors.  Tracked sequences cannot use this: the
  * guess of pair k+1 needs the result of pair k (manager_class.cpp:2602-2707). */
 int lk_set_pairs_in_flight(lk_engine *e, int n);
 /* block until everything queued by this engine has finished */
