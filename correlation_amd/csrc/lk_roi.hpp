@@ -8,9 +8,11 @@
 //   blob         polygon_class.cpp:224-429 (ear clipping + per-triangle scan fill)
 // plus the per-level decimation and centres of pyramid_class.cpp:289-362.
 #pragma once
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 namespace lkroi {
@@ -272,8 +274,39 @@ public:
         return false; // degenerate input (the reference would not terminate)
     }
     emit(P.v_[P.head_].pv, P.head_, P.v_[P.head_].nx);
-    for (size_t k = 0; k + 5 < tris.size(); k += 6)
-      fill_triangle(&tris[k], xy);
+    // Scan fill, triangle by triangle in clipping order.  Large blobs: the triangles are filled
+    // by a few threads into lists of their own and joined in that order (same samples, same order).
+    const size_t n_tri = tris.size() / 6;
+    double area2 = 0.0;
+    for (size_t t = 0; t < n_tri; ++t) {
+      const float *q = &tris[6 * t];
+      area2 += std::fabs((double)(q[2] - q[0]) * (q[5] - q[1]) - (double)(q[4] - q[0]) * (q[3] - q[1]));
+    }
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t workers = std::min<size_t>({n_tri, 16, hw ? hw : 1});
+    if (area2 < 2.0 * 262144.0 || workers < 2) { // fewer than ~2.6e5 samples: not worth the threads
+      for (size_t t = 0; t < n_tri; ++t)
+        fill_triangle(&tris[6 * t], xy);
+      return true;
+    }
+    std::vector<std::vector<float>> part(n_tri);
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+      for (size_t t = next.fetch_add(1); t < n_tri; t = next.fetch_add(1))
+        fill_triangle(&tris[6 * t], part[t]);
+    };
+    std::vector<std::thread> th;
+    for (size_t w = 1; w < workers; ++w)
+      th.emplace_back(work);
+    work();
+    for (std::thread &x : th)
+      x.join();
+    size_t total = xy.size();
+    for (const std::vector<float> &v : part)
+      total += v.size();
+    xy.reserve(total);
+    for (const std::vector<float> &v : part)
+      xy.insert(xy.end(), v.begin(), v.end());
     return true;
   }
 };

@@ -150,6 +150,15 @@ def test_host_roi_code_equals_oracle_and_reference_goldens(engine_lib, oracle):
         got = np.zeros((max(n, 1), 2), np.float32)
         L.lk_roi_blob_points(_ffi.fptr(contour), len(contour), _ffi.fptr(got), n)
         assert n == count and got[:n].tobytes() == np.ascontiguousarray(want, np.float32).reshape(-1, 2)[:n].tobytes(), c
+    # a blob large enough for the threaded scan fill: triangles filled in parallel, joined in clipping order
+    ang = 2 * np.pi * np.arange(40) / 40
+    rad = np.where(np.arange(40) % 2 == 0, 520.0, 330.0)
+    star = np.stack([700.3 + rad * np.cos(ang), 650.7 + rad * np.sin(ang)], 1).astype(np.float32)
+    n = L.lk_roi_blob_points(_ffi.fptr(star), len(star), None, 0)
+    got = np.zeros((n, 2), np.float32)
+    L.lk_roi_blob_points(_ffi.fptr(star), len(star), _ffi.fptr(got), n)
+    want = oracle.blob_points(star)
+    assert n == len(want) > 400000 and got.tobytes() == want.tobytes()
     # decimation
     rng = np.random.default_rng(4)
     pts = (rng.random((500, 2)) * 64).astype(np.float32)
