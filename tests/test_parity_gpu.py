@@ -909,10 +909,12 @@ def test_device_rebuilt_lists_equal_the_host_rebuild(monkeypatch, given_centers,
             e.set_sector_points(3, oracle_free_rect(100, 200, 104, 203), center=(102.0, 201.5))
             e.set_sector_points(4, np.round(pts), center=(155.25, 140.5))
             e.set_sector_points(5, oracle_free_rect(180, 160, 260, 250), center=(220.0, 205.0))
+            e.set_sector_points(6, oracle_free_rect(2, 2, 30, 34), center=(16.0, 18.0))   # fails: leaves the image
         else:
             e.resetPolygon_rect(3, 100, 200, 104, 203)          # 5 x 4 samples: starved upper levels
             e.set_sector_points(4, pts, center=(155.25, 140.5))
             e.resetPolygon_rect(5, 180, 160, 260, 250)
+            e.resetPolygon_rect(6, 2, 2, 30, 34)                # fails: leaves the image
         e.commit_sectors()
         S = e.n_sectors
         out = []
