@@ -126,10 +126,12 @@ struct lk_tracker {
   std::vector<lk_frame_result> res, before; // frame_results[]; state before begin_frame
   std::string report;                 // the CSV header
   std::vector<std::string> report_blocks; // + the rows, one block per formatting thread and frame
+  std::vector<lk_frame_result> report_res; // the records the rows in the making are read from
+  std::future<void> report_job;            // formats report_res into the newest report_blocks
   bool report_enabled = true;
   std::string err;
   bool begun = false;
-  Workers workers;
+  Workers workers, report_workers;
   // scratch of lk_sequence_frame (kept: three multi-megabyte buffers per frame otherwise)
   std::vector<lk_sector_command> seq_cmds;
   std::vector<float> seq_guesses;
@@ -259,10 +261,10 @@ static void initialize_report(lk_tracker *t) { // manager_class.cpp:2473-2525
 }
 
 // one report row per sector of [first, last), appended to r
-static void report_rows(const lk_tracker *t, size_t first, size_t last, int frame, const char *und, const char *def,
-                        std::string &r) {
+static void report_rows(const lk_tracker *t, const lk_frame_result *res, size_t first, size_t last, int frame,
+                        const char *und, const char *def, std::string &r) {
   for (size_t i = first; i < last; ++i) {
-    const lk_frame_result &s = t->res[i];
+    const lk_frame_result &s = res[i];
     put(r, frame);
     r += ',';
     r += und;
@@ -298,27 +300,47 @@ static void report_rows(const lk_tracker *t, size_t first, size_t last, int fram
   }
 }
 
+static void wait_for_report(lk_tracker *t) {
+  if (t->report_job.valid())
+    t->report_job.get();
+}
+
 // manager_class.cpp:2430-2471.  ~35 number conversions per sector: on grids of tens of
 // thousands of sectors the rows are formatted by a few threads, each on its own block of
-// sectors, and joined in sector order (the text is the same as the sequential loop's).
+// sectors, and joined in sector order (the text is the same as the sequential loop's) - and
+// they are formatted BEHIND the caller: the frame's records are copied, a background job
+// formats the copy with helper threads of its own while the caller goes on to the next pair;
+// whoever needs the text (lk_tracker_report, the next frame's rows, the destructor) waits.
 static void add_frame_to_report(lk_tracker *t, int frame, const char *und, const char *def) {
   if (!t->report_enabled)
     return;
+  wait_for_report(t);
   const size_t S = t->res.size(), kRowsPerBlock = 2048, kMaxBlocks = 16;
   const size_t blocks = std::max<size_t>(1, std::min(S / kRowsPerBlock, kMaxBlocks));
   const size_t base = t->report_blocks.size();
   t->report_blocks.resize(base + blocks); // blocks are joined only when the text is asked for
-  std::string *part = &t->report_blocks[base];
   // fixed row blocks (whatever the number of threads that format them): block b = rows
   // [S*b/blocks, S*(b+1)/blocks)
-  t->workers.run(blocks, 1, [&](size_t b0, size_t b1) {
-    for (size_t b = b0; b < b1; ++b) {
-      const size_t first = S * b / blocks, last = S * (b + 1) / blocks;
-      std::string rows; // (a local: the block headers sit side by side in one cache line)
-      rows.reserve((last - first) * (size_t)(96 + 26 * t->P) + 64);
-      report_rows(t, first, last, frame, und, def, rows);
-      part[b] = std::move(rows);
-    }
+  auto format = [t, S, blocks, base, frame](const lk_frame_result *res, const std::string &u, const std::string &d,
+                                            Workers &pool) {
+    std::string *part = &t->report_blocks[base];
+    pool.run(blocks, 1, [&](size_t b0, size_t b1) {
+      for (size_t b = b0; b < b1; ++b) {
+        const size_t first = S * b / blocks, last = S * (b + 1) / blocks;
+        std::string rows; // (a local: the block headers sit side by side in one cache line)
+        rows.reserve((last - first) * (size_t)(96 + 26 * t->P) + 64);
+        report_rows(t, res, first, last, frame, u.c_str(), d.c_str(), rows);
+        part[b] = std::move(rows);
+      }
+    });
+  };
+  if (blocks < 2) { // small grids: not worth a copy and a thread
+    format(t->res.data(), und, def, t->workers);
+    return;
+  }
+  t->report_res = t->res;
+  t->report_job = std::async(std::launch::async, [t, format, u = std::string(und), d = std::string(def)] {
+    format(t->report_res.data(), u, d, t->report_workers);
   });
 }
 
@@ -486,7 +508,12 @@ int lk_tracker_create(const lk_tracker_config *cfg, lk_tracker **out) {
   return LK_ERROR_NONE;
 }
 
-void lk_tracker_destroy(lk_tracker *t) { delete t; }
+void lk_tracker_destroy(lk_tracker *t) {
+  if (!t)
+    return;
+  wait_for_report(t);
+  delete t;
+}
 
 const char *lk_tracker_last_error(const lk_tracker *t) { return t ? t->err.c_str() : "null tracker"; }
 
@@ -739,6 +766,7 @@ int lk_tracker_get_results(const lk_tracker *t, lk_frame_result *out) {
 int lk_tracker_report(const lk_tracker *t, char *buf, size_t cap, size_t *needed) {
   if (!t)
     return LK_ERROR_BAD_DOMAIN;
+  wait_for_report(const_cast<lk_tracker *>(t)); // the last frame's rows may still be in the making
   size_t size = t->report.size();
   for (const std::string &x : t->report_blocks)
     size += x.size();
