@@ -1058,6 +1058,36 @@ static void rewarp_one(HostSector &h, int model, const float *p, const float *ce
 
 static int rewarp_on_device(lk_engine *e, const float *centers_xy, const float *offsets_xy = nullptr);
 
+// A grid of implicit rectangles that only moved (Lagrangian description): sizes, classes, launch
+// order and the (empty) explicit lists are what they were; only the per-level rectangles, the
+// centres and - through the parity of the new positions - the starved-level flags change.
+static int recommit_rects(lk_engine *e) {
+  const int S = e->S;
+  const lk_config &cfg = e->cfg;
+  HIPCHK(hipSetDevice(cfg.device));
+  HIPCHK(hipStreamSynchronize(e->stream)); // the previous uploads from these host tables are done
+  const int first = cfg.py_start == 0 ? cfg.py_step : cfg.py_start; // pyramid_class.cpp:299
+  std::vector<int> levels{0};
+  for (int l = first; l <= cfg.py_stop; l += cfg.py_step)
+    levels.push_back(l);
+  for (int s = 0; s < S; ++s) {
+    const HostSector &hs = e->hs[(size_t)s];
+    e->h_center[2 * (size_t)s] = hs.cx;
+    e->h_center[2 * (size_t)s + 1] = hs.cy;
+    for (int l : levels) { // (the rule of commit_impl)
+      int xs = ceil_shift(hs.x0, l), xe = floor_shift(hs.x1, l);
+      int ys = ceil_shift(hs.y0, l), ye = floor_shift(hs.y1, l);
+      int w = std::max(0, xe - xs + 1), h = std::max(0, ye - ys + 1);
+      e->h_rect[l][(size_t)s] = make_int4(xs, ys, std::max(w, 1), w * h);
+    }
+  }
+  for (int l : levels)
+    HIPCHK(hipMemcpyAsync(e->d_rect[l].p, e->h_rect[l].data(), (size_t)S * sizeof(int4), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->d_center.p, e->h_center.data(), 2 * (size_t)S * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  e->stats_valid = false;
+  return refresh_starved(e);
+}
+
 int lk_translate_sectors(lk_engine *e, const float *offsets_xy, const float *centers_xy) {
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
@@ -1081,12 +1111,35 @@ int lk_translate_sectors(lk_engine *e, const float *offsets_xy, const float *cen
     if (rc)
       return rc;
   }
-  e->hs_backup = e->hs;
+  e->hs_backup.resize(e->hs.size());
   e->backup_on_device = false;
-  for (int s = 0; s < e->S; ++s)
-    translate_one(e->hs[(size_t)s], offsets_xy[2 * (size_t)s], offsets_xy[2 * (size_t)s + 1],
-                  centers_xy ? centers_xy + 2 * (size_t)s : nullptr);
-  return commit_impl(e, true);
+  // sectors are independent: blocks of them on a few threads when there are tens of thousands
+  const int S = e->S;
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int workers = std::max(1, std::min({S / 8192, 8, (int)(hw ? hw : 1)}));
+  std::vector<char> all_rect((size_t)workers, 1);
+  auto work = [&](int w) {
+    bool rects = true;
+    for (int s = (int)((int64_t)S * w / workers), last = (int)((int64_t)S * (w + 1) / workers); s < last; ++s) {
+      HostSector &h = e->hs[(size_t)s];
+      e->hs_backup[(size_t)s] = h;
+      rects = rects && h.is_rect;
+      translate_one(h, offsets_xy[2 * (size_t)s], offsets_xy[2 * (size_t)s + 1],
+                    centers_xy ? centers_xy + 2 * (size_t)s : nullptr);
+      rects = rects && h.is_rect;
+    }
+    all_rect[(size_t)w] = rects;
+  };
+  std::vector<std::thread> th;
+  for (int w = 1; w < workers; ++w)
+    th.emplace_back(work, w);
+  work(0);
+  for (std::thread &t : th)
+    t.join();
+  bool rects_only = true;
+  for (char r : all_rect)
+    rects_only = rects_only && r;
+  return rects_only ? recommit_rects(e) : commit_impl(e, true);
 }
 
 // Strict Lagrangian description (manager_class.cpp:369-380): the deformed positions of the
