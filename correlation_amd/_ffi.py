@@ -89,6 +89,8 @@ SYMBOLS = {
     "lk_correlate": (C.c_int, [_P, C.c_int, _F, _P]),
     "lk_correlate_all": (C.c_int, [_P, _F, _P]),
     "lk_correlate_all_device": (C.c_int, [_P, _P, _P]),
+    "lk_correlate_all_async": (C.c_int, [_P]),
+    "lk_wait_results": (C.c_int, [_P, _P]),
     "lk_adjust_initial_guess": (C.c_int, [_P, C.c_int, C.c_int, _F, C.c_float, C.c_float]),
     "lk_get_guesses": (C.c_int, [_P, _F]),
     "lk_evaluate": (C.c_int, [_P, C.c_int, C.c_int, _F, _F, _F, _F, _I]),

@@ -187,6 +187,10 @@ struct lk_engine {
   DevBuf<uint32_t> d_team_arrivals;
   DevBuf<float> d_scratch; // 64 floats for the stand-alone entry points
   DevBuf<float2> d_warp;
+  lk_result *h_results = nullptr; // pinned: where lk_correlate_all_async leaves the records
+  size_t h_results_n = 0;
+  hipEvent_t ev_results = nullptr;
+  bool results_pending = false;
   bool stats_valid = false;
   lk_stats stats{};
 
@@ -297,6 +301,10 @@ void lk_destroy(lk_engine *e) {
       (void)hipEventDestroy(ev);
   if (e->ev_fork)
     (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_results)
+    (void)hipEventDestroy(e->ev_results);
+  if (e->h_results)
+    (void)hipHostFree(e->h_results);
   if (e->own_stream)
     (void)hipStreamDestroy(e->own_stream);
   if (e->nxt_stream)
@@ -1598,6 +1606,47 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
     e->solve_timed = true;
   }
   e->stats_valid = false;
+  return LK_ERROR_NONE;
+}
+
+int lk_correlate_all_async(lk_engine *e) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (e->results_pending)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_correlate_all_async: the previous solve has not been waited for");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  int rc = refresh_level_views(e);
+  if (rc)
+    return rc;
+  if (e->h_results_n < (size_t)e->S) {
+    if (e->h_results)
+      HIPCHK(hipHostFree(e->h_results));
+    e->h_results = nullptr;
+    e->h_results_n = 0;
+    HIPCHK(hipHostMalloc((void **)&e->h_results, (size_t)e->S * sizeof(lk_result), hipHostMallocDefault));
+    e->h_results_n = (size_t)e->S;
+  }
+  if (!e->ev_results)
+    HIPCHK(hipEventCreateWithFlags(&e->ev_results, hipEventDisableTiming));
+  rc = launch_all(e, e->d_guess.p, e->d_result.p);
+  if (rc)
+    return rc;
+  HIPCHK(hipMemcpyAsync(e->h_results, e->d_result.p, (size_t)e->S * sizeof(lk_result), hipMemcpyDeviceToHost,
+                        e->stream));
+  HIPCHK(hipEventRecord(e->ev_results, e->stream));
+  e->results_pending = true;
+  return LK_ERROR_NONE;
+}
+
+int lk_wait_results(lk_engine *e, lk_result *out) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!e->results_pending || !out)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_wait_results: no solve outstanding / null buffer");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipEventSynchronize(e->ev_results));
+  e->results_pending = false;
+  std::memcpy(out, e->h_results, (size_t)e->S * sizeof(lk_result));
   return LK_ERROR_NONE;
 }
 

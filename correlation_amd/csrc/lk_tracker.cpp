@@ -80,7 +80,7 @@ public:
   }
 
 private:
-  static constexpr size_t kMaxThreads = 16;
+  static constexpr size_t kMaxThreads = 32;
   void loop(size_t index) {
     size_t seen = 0;
     for (;;) {
@@ -315,7 +315,7 @@ static void add_frame_to_report(lk_tracker *t, int frame, const char *und, const
   if (!t->report_enabled)
     return;
   wait_for_report(t);
-  const size_t S = t->res.size(), kRowsPerBlock = 2048, kMaxBlocks = 16;
+  const size_t S = t->res.size(), kRowsPerBlock = 1024, kMaxBlocks = 32;
   const size_t blocks = std::max<size_t>(1, std::min(S / kRowsPerBlock, kMaxBlocks));
   const size_t base = t->report_blocks.size();
   t->report_blocks.resize(base + blocks); // blocks are joined only when the text is asked for
@@ -790,6 +790,43 @@ int lk_tracker_report(const lk_tracker *t, char *buf, size_t cap, size_t *needed
 // ------------------------------------------------------------------------------------
 // frame loop on an engine
 // ------------------------------------------------------------------------------------
+// frame 0: the tracker's commands become the engine's sectors
+static int register_sectors(lk_engine *e, lk_tracker *t, const std::vector<lk_sector_command> &cmds) {
+  const int S = (int)cmds.size();
+  int rc = lk_clear_sectors(e);
+  bool annular = S > 0;
+  for (int s = 0; s < S && annular; ++s)
+    annular = cmds[(size_t)s].kind == LK_SECTOR_ANNULAR && cmds[(size_t)s].as == cmds[0].as;
+  if (annular && !rc) { // every sector of the annulus in one call: rasterised on several host threads
+    std::vector<float> q(6 * (size_t)S);
+    for (int s = 0; s < S; ++s) {
+      const lk_sector_command &c = cmds[(size_t)s];
+      const float v[6] = {c.r, c.dr, c.a, c.da, c.cx, c.cy};
+      std::memcpy(&q[6 * (size_t)s], v, sizeof(v));
+    }
+    rc = lk_set_sectors_annular(e, 0, S, q.data(), cmds[0].as);
+  }
+  for (int s = 0; s < S && !rc && !annular; ++s) {
+    const lk_sector_command &c = cmds[(size_t)s];
+    switch (c.kind) {
+    case LK_SECTOR_RECT: rc = lk_set_sector_rect(e, s, c.x0, c.y0, c.x1, c.y1); break;
+    case LK_SECTOR_ANNULAR: rc = lk_set_sector_annular(e, s, c.r, c.dr, c.a, c.da, c.cx, c.cy, c.as); break;
+    case LK_SECTOR_BLOB: {
+      const float *xy = nullptr;
+      int n = 0;
+      rc = lk_tracker_blob_contour(t, &xy, &n);
+      if (!rc)
+        rc = lk_set_sector_blob(e, s, xy, n);
+      break;
+    }
+    default: rc = LK_ERROR_BAD_DOMAIN; break;
+    }
+  }
+  if (!rc)
+    rc = lk_commit_sectors(e);
+  return rc;
+}
+
 int lk_sequence_frame(lk_engine *e, lk_tracker *t, int frame, const char *und_name, const char *def_name,
                       int *stop_sequence) {
   if (!e || !t)
@@ -803,37 +840,7 @@ int lk_sequence_frame(lk_engine *e, lk_tracker *t, int frame, const char *und_na
   if (rc)
     return rc;
   if (frame == 0) {
-    rc = lk_clear_sectors(e);
-    bool annular = S > 0;
-    for (int s = 0; s < S && annular; ++s)
-      annular = cmds[(size_t)s].kind == LK_SECTOR_ANNULAR && cmds[(size_t)s].as == cmds[0].as;
-    if (annular && !rc) { // every sector of the annulus in one call: rasterised on several host threads
-      std::vector<float> q(6 * (size_t)S);
-      for (int s = 0; s < S; ++s) {
-        const lk_sector_command &c = cmds[(size_t)s];
-        const float v[6] = {c.r, c.dr, c.a, c.da, c.cx, c.cy};
-        std::memcpy(&q[6 * (size_t)s], v, sizeof(v));
-      }
-      rc = lk_set_sectors_annular(e, 0, S, q.data(), cmds[0].as);
-    }
-    for (int s = 0; s < S && !rc && !annular; ++s) {
-      const lk_sector_command &c = cmds[(size_t)s];
-      switch (c.kind) {
-      case LK_SECTOR_RECT: rc = lk_set_sector_rect(e, s, c.x0, c.y0, c.x1, c.y1); break;
-      case LK_SECTOR_ANNULAR: rc = lk_set_sector_annular(e, s, c.r, c.dr, c.a, c.da, c.cx, c.cy, c.as); break;
-      case LK_SECTOR_BLOB: {
-        const float *xy = nullptr;
-        int n = 0;
-        rc = lk_tracker_blob_contour(t, &xy, &n);
-        if (!rc)
-          rc = lk_set_sector_blob(e, s, xy, n);
-        break;
-      }
-      default: rc = LK_ERROR_BAD_DOMAIN; break;
-      }
-    }
-    if (!rc)
-      rc = lk_commit_sectors(e);
+    rc = register_sectors(e, t, cmds);
   } else if (S > 0 && cmds[0].kind != LK_SECTOR_KEEP) {
     std::vector<float> off(2 * (size_t)S), cen(2 * (size_t)S);
     for (int s = 0; s < S; ++s) {
@@ -886,6 +893,96 @@ int lk_sequence_run(lk_engine *e, lk_tracker *t, int n_frames, lk_frame_provider
     rc = lk_set_image(e, LK_IMG_DEF, f1.px, f1.rows, f1.cols, f1.step);
   std::string und_name = f0.name, def_name = f1.name;
   const int pairs = n_frames - 1;
+  // Eulerian description on a rectangular grid, no stop policy: the guess of pair k+1 is a function
+  // of the engine-held results alone (lk_adjust_initial_guess on the device = adjust_initial_guess,
+  // manager_class.cpp:2602-2707), so pair k+1 is launched as soon as pair k's records are back and
+  // the tracker's bookkeeping of pair k (update_results, global results, report) runs BEHIND that
+  // solve instead of between two solves.
+  const char *sync_env = std::getenv("LK_SEQ_SYNC"); // test / comparison hook
+  const bool overlapped = !rc && t->cfg.deformation == LK_DEF_EULERIAN && t->cfg.error_mode == LK_ERRMODE_CONTINUE &&
+                          t->cfg.domain_type == LK_DOMAIN_RECT && !(sync_env && std::atoi(sync_env) != 0);
+  if (overlapped) {
+    const char *check_env = std::getenv("LK_SEQ_CHECK"); // tests: device guesses == the tracker's, bit for bit
+    const bool check = check_env && std::atoi(check_env) != 0;
+    const int S = lk_tracker_sector_count(t);
+    const bool velocity = t->cfg.reference_image == LK_REF_FIRST;
+    float gg[6] = {0, 0, 0, 0, 0, 0};
+    for (int p = 0; p < t->P; ++p)
+      gg[p] = t->cfg.global_guess[p];
+    std::vector<lk_sector_command> &cmds = t->seq_cmds;
+    std::vector<float> &guesses = t->seq_guesses;
+    std::vector<lk_result> &results = t->seq_results;
+    cmds.resize((size_t)S);
+    guesses.resize(6 * (size_t)S);
+    results.resize((size_t)S);
+    std::vector<float> device_guesses(check ? 6 * (size_t)S : 0);
+    auto launch = [&](int k) {
+      int r = lk_adjust_initial_guess(e, k, velocity ? 1 : 0, gg, t->x_center, t->y_center);
+      if (!r && check)
+        r = lk_get_guesses(e, device_guesses.data());
+      return r ? r : lk_correlate_all_async(e);
+    };
+    auto verify = [&]() { // (check mode) what the device solved from is what the tracker would have sent
+      return !check || std::memcmp(device_guesses.data(), guesses.data(), device_guesses.size() * sizeof(float)) == 0;
+    };
+    rc = lk_tracker_begin_frame(t, 0, cmds.data(), guesses.data());
+    if (!rc)
+      rc = register_sectors(e, t, cmds);
+    if (!rc)
+      rc = launch(0);
+    if (!rc && !verify())
+      rc = t->fail(LK_ERROR_BAD_DOMAIN, "lk_sequence_run: device guesses differ from the tracker's (frame 0)");
+    Frame fn;
+    std::future<int> next;
+    auto prefetch = [&](int index) { // frame `index` -> the next-image slot, behind the running solve
+      next = std::async(std::launch::async, [&, index] {
+        fn = fetch(index);
+        return fn.px ? lk_set_image(e, LK_IMG_NXT, fn.px, fn.rows, fn.cols, fn.step) : (int)LK_ERROR_BAD_DOMAIN;
+      });
+    };
+    if (!rc && n_frames > 2)
+      prefetch(2);
+    for (int k = 0; k < pairs && !rc; ++k) {
+      rc = lk_wait_results(e, results.data());
+      const std::string und_k = und_name, def_k = def_name;
+      if (next.valid()) {
+        const int nrc = next.get();
+        if (!rc && nrc) // error_multiThread in the reference (manager_class.cpp:1470-1475)
+          rc = nrc;
+      }
+      if (!rc && k + 1 < pairs) { // image roles of the next pair (manager_class.cpp:1386-1407, :166-243)
+        if (t->cfg.reference_image == LK_REF_PREVIOUS) {
+          rc = lk_rotate_und_from_def(e);
+          und_name = def_name;
+        }
+        if (!rc)
+          rc = lk_rotate_def_from_nxt(e);
+        def_name = fn.name;
+        if (!rc)
+          rc = launch(k + 1);
+        if (!rc && k + 3 < n_frames)
+          prefetch(k + 3);
+      }
+      if (rc)
+        break;
+      int first_unsolved = S, stop = 0; // (never a stop: the continue policy is a condition of this path)
+      rc = lk_tracker_end_frame(t, k, und_k.c_str(), def_k.c_str(), results.data(), &first_unsolved, &stop);
+      if (!rc && pairs_done)
+        *pairs_done = k + 1;
+      if (!rc && k + 1 < pairs) {
+        rc = lk_tracker_begin_frame(t, k + 1, cmds.data(), guesses.data()); // bookkeeping; the solve is already running
+        if (!rc && !verify())
+          rc = t->fail(LK_ERROR_BAD_DOMAIN, "lk_sequence_run: device guesses differ from the tracker's");
+      }
+    }
+    if (next.valid())
+      (void)next.get();
+    if (rc) { // leave no solve outstanding behind an error
+      std::vector<lk_result> drop((size_t)S);
+      (void)lk_wait_results(e, drop.data());
+    }
+    return rc;
+  }
   for (int k = 0; k < pairs && !rc; ++k) {
     // load and upload frame k + 2 while pair k is being solved (manager_class.cpp:1438-1447:
     // std::async + set_next_image; here the upload and pyramid build run on the engine's

@@ -237,6 +237,15 @@ class HipCorrelationEngine:
         self._chk(self.lib.lk_correlate_all_device(self._h, C.c_void_p(d_guesses_ptr),
                                                    C.c_void_p(d_results_ptr)))
 
+    def correlate_all_async(self):
+        """lk_correlate_all_async: the engine-held guesses, no waiting; wait_results() fetches."""
+        self._chk(self.lib.lk_correlate_all_async(self._h))
+
+    def wait_results(self):
+        out = np.zeros(self.n_sectors, RESULT_DTYPE)
+        self._chk(self.lib.lk_wait_results(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def adjust_initial_guess(self, frame, constant_velocity, global_guess, global_center):
         g = np.zeros(6, np.float32)
         g[:len(global_guess)] = global_guess

@@ -233,6 +233,12 @@ int lk_correlate_all(lk_engine *e, const float *guesses, lk_result *out);
 /* same with device buffers, asynchronous on the engine's stream; d_guesses may be NULL
  * to use the engine-held guesses written by lk_adjust_initial_guess */
 int lk_correlate_all_device(lk_engine *e, const void *d_guesses, void *d_results);
+/* lk_correlate_all with the engine-held guesses (lk_adjust_initial_guess) that does not wait: the
+ * records follow the solve into an engine-owned pinned buffer; lk_wait_results blocks until they
+ * are there and copies them to out [S].  One solve may be outstanding.  A frame loop uses the
+ * pair to keep the host's per-frame bookkeeping off the GPU's critical path (lk_sequence_run). */
+int lk_correlate_all_async(lk_engine *e);
+int lk_wait_results(lk_engine *e, lk_result *out);
 
 /* managerClass::adjust_initial_guess (manager_class.cpp:2602-2707), batched on the
  * device for every sector: frame 0 -> global guess + strain*(sector centre - global

@@ -953,6 +953,36 @@ def test_device_rebuilt_lists_equal_the_host_rebuild(monkeypatch, given_centers,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("model,reference", [(ca.FM_UVUXUYVXVY, 0), (ca.FM_UVQ, 0), (ca.FM_UV, 1), (ca.FM_U, 0),
+                                             (ca.FM_UVUXUYVXVY, 1)])
+def test_overlapped_frame_loop_equals_the_synchronous_one(monkeypatch, model, reference):
+    """Eulerian sequences on a rectangular grid launch pair k+1 from device-computed guesses before
+    the tracker has digested pair k (lk_sequence_run).  The report must be the text of the
+    one-pair-at-a-time loop (LK_SEQ_SYNC=1), and the guesses the device used must be the tracker's
+    own, bit for bit (LK_SEQ_CHECK=1 makes the loop fail otherwise)."""
+    from correlation_amd import tracker as tk
+    frames = ca.speckle.speckle_sequence(320, 288, 6, velocity=(0.8, -0.45), dilation=5e-4, seed=21)
+    names = [f"f{i}" for i in range(len(frames))]
+    guess = [0.4, -0.2, 1e-3, 5e-4, -5e-4, 2e-3]
+
+    def run(sync):
+        monkeypatch.setenv("LK_SEQ_SYNC", "1" if sync else "0")
+        monkeypatch.setenv("LK_SEQ_CHECK", "1")
+        e = ca.HipCorrelationEngine(fitting_model=model)
+        e.set_batch_invariant(True)
+        t = tk.SequenceTracker(model, tk.DOMAIN_RECT, tk.DEF_EULERIAN, reference, tk.ERRMODE_CONTINUE, guess, lib=e.lib)
+        t.set_rect_domain(30.0, 34.0, 289.0, 251.0, 160.0, 144.0, 9, 7)
+        assert tk.run_sequence(e, t, frames, names) == len(frames) - 1
+        text, res = t.report(), t.results().tobytes()
+        e.close(), t.close()
+        return text, res
+
+    want, got = run(True), run(False)
+    assert got[0] == want[0] and got[1] == want[1]
+    assert want[0].count("\n") == 1 + 5 * 63
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", [0, 1])
 def test_update_sector_equals_the_frame_loop(mode):
     """CudaClass::updatePolygon's call shape (one sector, the engine's own last record) must move
