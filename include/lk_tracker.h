@@ -126,7 +126,11 @@ int lk_sequence_frame(lk_engine *e, lk_tracker *t, int frame, const char *und_na
 typedef const uint8_t *(*lk_frame_provider)(void *user, int index, int *rows, int *cols, int *step,
                                             const char **name);
 /* perform_multiframe_correlation (manager_class.cpp:1296-1496): n_frames images, n_frames - 1
- * pairs.  *pairs_done receives the number of pairs correlated. */
+ * pairs.  *pairs_done receives the number of pairs correlated.
+ * Eulerian description + rectangular domain + continue policy: pair k+1 is launched from the
+ * device-computed guesses (lk_adjust_initial_guess) as soon as the records of pair k are back,
+ * and the tracker's bookkeeping of pair k runs behind that solve - same frame_results and report,
+ * bit for bit, as the one-pair-at-a-time loop every other configuration uses. */
 int lk_sequence_run(lk_engine *e, lk_tracker *t, int n_frames, lk_frame_provider provider, void *user,
                     int *pairs_done);
 
