@@ -980,6 +980,10 @@ def test_overlapped_frame_loop_equals_the_synchronous_one(monkeypatch, model, re
     want, got = run(True), run(False)
     assert got[0] == want[0] and got[1] == want[1]
     assert want[0].count("\n") == 1 + 5 * 63
+    all_frames = frames
+    for n in (2, 3):        # one pair (nothing to prefetch) and two
+        frames = all_frames[:n]
+        assert run(True) == run(False)
 
 
 @pytest.mark.gpu
