@@ -1545,6 +1545,12 @@ static int launch_groups(lk_engine *e, LkSolveArgs &a, int group, int c, int fir
   return LK_ERROR_NONE;
 }
 
+// Team workgroups wait for each other, so two team launches that are both only partly resident
+// would wait forever.  One engine never has two in flight; engines of one process take turns:
+// every team launch waits for the previous one on the same device (whoever issued it).
+static std::mutex g_team_mu;
+static hipEvent_t g_team_done[64] = {};
+
 static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
   if (e->timing)
     HIPCHK(hipEventRecord(e->ev_s0, e->stream));
@@ -1579,11 +1585,21 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
     a.n_sectors = n;
     a.queue = e->d_queue.p + 8 * c;
     a.safe = e->force_safe ? 1 : 0;
+    std::unique_lock<std::mutex> team_turn;
+    hipEvent_t *team_done = nullptr;
     if (c == kTeamClass) {
       a.team_w = e->team_w;
       a.team_min_samples = e->team_min_samples;
       a.team_partials = e->d_team_partials.p;
       a.team_arrivals = e->d_team_arrivals.p;
+      if (e->team_w > 1 && e->cfg.device >= 0 && e->cfg.device < 64) {
+        team_turn = std::unique_lock<std::mutex>(g_team_mu);
+        team_done = &g_team_done[e->cfg.device];
+        if (!*team_done)
+          HIPCHK(hipEventCreateWithFlags(team_done, hipEventDisableTiming));
+        else
+          HIPCHK(hipStreamWaitEvent(st, *team_done, 0));
+      }
     }
     if (e->class_starved[c]) { // coarsest level(s) first, one lane per sector (+ finisher)
       int rc = launch_starved(e, a, c, e->class_begin[c], st);
@@ -1595,6 +1611,9 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
       if (rc)
         return rc;
     }
+    if (team_done)
+      HIPCHK(hipEventRecord(*team_done, st));
+    team_turn = std::unique_lock<std::mutex>();
     if (st != e->stream) {
       HIPCHK(hipEventRecord(e->ev_join[c], st));
       HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join[c], 0));
@@ -1707,11 +1726,21 @@ int lk_correlate(lk_engine *e, int sector, float *guess_inout, lk_result *out) {
   a.n_sectors = 1;
   a.queue = e->d_queue.p;
   a.safe = e->force_safe ? 1 : 0;
+  std::unique_lock<std::mutex> team_turn;
+  hipEvent_t *team_done = nullptr;
   if (e->h_class[(size_t)sector] == kTeamClass) {
     a.team_w = e->team_w;
     a.team_min_samples = e->team_min_samples;
     a.team_partials = e->d_team_partials.p;
     a.team_arrivals = e->d_team_arrivals.p;
+    if (e->team_w > 1 && e->cfg.device >= 0 && e->cfg.device < 64) { // (see launch_all)
+      team_turn = std::unique_lock<std::mutex>(g_team_mu);
+      team_done = &g_team_done[e->cfg.device];
+      if (!*team_done)
+        HIPCHK(hipEventCreateWithFlags(team_done, hipEventDisableTiming));
+      else
+        HIPCHK(hipStreamWaitEvent(e->stream, *team_done, 0));
+    }
   }
   if (e->timing)
     HIPCHK(hipEventRecord(e->ev_s0, e->stream));
@@ -1725,6 +1754,9 @@ int lk_correlate(lk_engine *e, int sector, float *guess_inout, lk_result *out) {
     if (rc)
       return rc;
   }
+  if (team_done)
+    HIPCHK(hipEventRecord(*team_done, e->stream));
+  team_turn = std::unique_lock<std::mutex>();
   if (e->timing) {
     HIPCHK(hipEventRecord(e->ev_s1, e->stream));
     e->solve_timed = true;

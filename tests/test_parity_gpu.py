@@ -311,6 +311,51 @@ def test_pairs_in_flight_give_the_records_of_a_lone_solve(speckle512):
         ca.HipCorrelationEngine().set_pairs_in_flight(0)
 
 
+def test_team_launches_of_two_engines_take_turns(monkeypatch, speckle512):
+    """Teams (several workgroups per sector that wait for each other) of different engines must
+    not be on the GPU half-resident at the same time: every team launch waits for the previous
+    one of the process.  Two engines queue team solves back to back on their own streams; each
+    must get the records of a lone solve."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipStreamCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+    hip.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    monkeypatch.setenv("LK_FORCE_TEAM", "4")    # every sector a team of 4 workgroups (tiny: cannot fill the GPU)
+    und, dfm = speckle512
+
+    def engine(stream=None):
+        e = ca.HipCorrelationEngine()
+        if stream is not None:
+            e.set_stream(stream.value)
+        e.set_undeformed_image(und)
+        e.set_deformed_image(dfm)
+        for s, (x0, y0) in enumerate(((40, 40), (260, 50), (60, 270), (250, 260))):
+            e.resetPolygon_rect(s, x0, y0, x0 + 200, y0 + 190)
+        e.commit_sectors()
+        return e
+
+    e = engine()
+    want = e.correlate_all()
+    assert (want["error_code"] == 0).all()
+    e.close()
+    streams, engines = [], []
+    for _ in range(2):
+        st = ctypes.c_void_p()
+        assert hip.hipStreamCreateWithFlags(ctypes.byref(st), 1) == 0
+        streams.append(st)
+        engines.append(engine(st))
+    for rep in range(4):
+        for e in engines:
+            e.adjust_initial_guess(0, False, np.zeros(6, np.float32), (256.0, 256.0))
+            e.correlate_all_async()
+        for e in engines:
+            got = e.wait_results()
+            assert got.tobytes() == want.tobytes(), rep
+    for e, st in zip(engines, streams):
+        e.close()
+        assert hip.hipStreamDestroy(st) == 0
+
+
 @pytest.mark.parametrize("interp", [ca.IM_NEAREST, ca.IM_BILINEAR, ca.IM_BICUBIC])
 def test_sampling_bit_exact(oracle, speckle512, interp):
     und, dfm = speckle512
