@@ -132,6 +132,7 @@ struct lk_tracker {
   std::string err;
   bool begun = false;
   Workers workers, report_workers;
+  size_t min_block = 4096; // sectors per block of the threaded loops (LK_TRACKER_MIN_BLOCK: test hook)
   // scratch of lk_sequence_frame (kept: three multi-megabyte buffers per frame otherwise)
   std::vector<lk_sector_command> seq_cmds;
   std::vector<float> seq_guesses;
@@ -315,7 +316,7 @@ static void add_frame_to_report(lk_tracker *t, int frame, const char *und, const
   if (!t->report_enabled)
     return;
   wait_for_report(t);
-  const size_t S = t->res.size(), kRowsPerBlock = 1024, kMaxBlocks = 32;
+  const size_t S = t->res.size(), kRowsPerBlock = std::min<size_t>(1024, t->min_block), kMaxBlocks = 32;
   const size_t blocks = std::max<size_t>(1, std::min(S / kRowsPerBlock, kMaxBlocks));
   const size_t base = t->report_blocks.size();
   t->report_blocks.resize(base + blocks); // blocks are joined only when the text is asked for
@@ -468,7 +469,7 @@ static void update_global_results(lk_tracker *t, const std::vector<float> &terms
   average_e = average_e / total_n;
   float und_ro = t->res[0].und_global_ro, und_ri = t->res[0].und_global_ri;
   float def_ri = 1.f + average_e * (und_ro / und_ri - 1.f);
-  t->workers.run(S, 4096, [&](size_t k0, size_t k1) {
+  t->workers.run(S, t->min_block, [&](size_t k0, size_t k1) {
     for (size_t k = k0; k < k1; ++k) {
       lk_frame_result &s = t->res[k];
       s.def_global_angle = average_angle;
@@ -503,6 +504,8 @@ int lk_tracker_create(const lk_tracker_config *cfg, lk_tracker **out) {
   lk_tracker *t = new lk_tracker();
   t->cfg = *cfg;
   t->P = n_params(cfg->fitting_model);
+  if (const char *f = std::getenv("LK_TRACKER_MIN_BLOCK"))
+    t->min_block = (size_t)std::max(1, std::atoi(f));
   initialize_report(t);
   *out = t;
   return LK_ERROR_NONE;
@@ -609,7 +612,7 @@ int lk_tracker_begin_frame(lk_tracker *t, int frame, lk_sector_command *commands
     lkroi::RectGrid g = lkroi::rect_grid(t->x_begin, t->y_begin, t->x_end, t->y_end, t->hs, t->vs);
     if (g.xdim < 0 || g.ydim < 0)
       return t->fail(LK_ERROR_BAD_DOMAIN, "lk_tracker_begin_frame: domain smaller than the grid");
-    t->workers.run((size_t)S, 4096, [&](size_t k0, size_t k1) {
+    t->workers.run((size_t)S, t->min_block, [&](size_t k0, size_t k1) {
       for (size_t kk = k0; kk < k1; ++kk) {
         const int k = (int)kk, i = k / t->vs, j = k % t->vs; // iSector = i*vs + j
         lk_frame_result &s = t->res[(size_t)k];
@@ -735,7 +738,7 @@ int lk_tracker_end_frame(lk_tracker *t, int frame, const char *und_name, const c
       }
   std::vector<float> &terms = t->global_terms_scratch;
   terms.resize(5 * (size_t)S);
-  t->workers.run((size_t)k, 4096, [&](size_t u0, size_t u1) {
+  t->workers.run((size_t)k, t->min_block, [&](size_t u0, size_t u1) {
     for (size_t u = u0; u < u1; ++u) {
       update_results(t, t->res[u], results[u]);
       global_terms(t->res[u], &terms[5 * u]);

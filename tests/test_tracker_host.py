@@ -88,8 +88,13 @@ CASES = [(tk.DOMAIN_RECT, tk.DEF_EULERIAN, tk.REF_FIRST, ca.FM_UVUXUYVXVY),
          (tk.DOMAIN_BLOB, tk.DEF_EULERIAN, tk.REF_PREVIOUS, ca.FM_U)]
 
 
+@pytest.mark.parametrize("threaded", [False, True])
 @pytest.mark.parametrize("domain,deformation,reference,model", CASES)
-def test_tracker_equals_manager_oracle(oracle, engine_lib, frames, domain, deformation, reference, model):
+def test_tracker_equals_manager_oracle(oracle, engine_lib, frames, monkeypatch, domain, deformation, reference, model,
+                                       threaded):
+    # threaded: one sector per block, so the helper threads of the per-sector loops and of the
+    # report (which only start on grids of thousands of sectors) run on these small domains too
+    monkeypatch.setenv("LK_TRACKER_MIN_BLOCK", "1" if threaded else "4096")
     guess = [0.5, -0.25, 1e-3, 0.0, 0.0, 2e-3]
     t = tk.SequenceTracker(model, domain, deformation, reference, tk.ERRMODE_CONTINUE, guess, lib=engine_lib)
 
@@ -137,9 +142,11 @@ def test_tracker_equals_manager_oracle(oracle, engine_lib, frames, domain, defor
     t.close()
 
 
-def test_tracker_stop_policy(oracle, engine_lib, frames):
+@pytest.mark.parametrize("threaded", [False, True])
+def test_tracker_stop_policy(oracle, engine_lib, frames, monkeypatch, threaded):
     """stopFrame / stopAll: sectors after the first failing one keep the state they had before
     the frame, and stopAll ends the sequence (manager_class.cpp:520-546, :1485-1486)."""
+    monkeypatch.setenv("LK_TRACKER_MIN_BLOCK", "1" if threaded else "4096")
     for mode in (tk.ERRMODE_STOP_FRAME, tk.ERRMODE_STOP_ALL, tk.ERRMODE_CONTINUE):
         t = tk.SequenceTracker(ca.FM_UV, tk.DOMAIN_RECT, tk.DEF_LAGRANGIAN, tk.REF_PREVIOUS, mode, lib=engine_lib)
         t.set_rect_domain(40.0, 44.0, 215.0, 211.0, 127.5, 127.5, 2, 2)
