@@ -8,11 +8,16 @@ achieved algorithmic HBM GB/s on the 2048^2 speckle pair of config C2.
 One "step" = one pass of the hot path over one image pair whose level-0 pixels are already
 resident in HBM: build both image pyramids (und, def), solve every sector of the ROI grid
 coarse-to-fine on the device, leave the 48-byte result records in HBM.
-N > 1 ("weak" scaling): one process per GPU; every step rank 0's deformed frame is
-broadcast over RCCL/xGMI (double-buffered: frame k+1 travels while frame k is solved), each
-rank correlates its own 10 000-sector grid (the C2 grid shifted by `rank` pixels - a denser
-measurement grid on the same pair) and the result records are all-gathered (asynchronously,
-double-buffered).  value = point-iterations of ALL ranks / max-over-ranks time.
+Steps are independent pairs: --inflight P (default 3) keeps P of them on the GPU at once, step
+k on engine k % P, each engine on its own HIP stream - the straggler tail of one solve is filled
+by the next pair's solve.  The `sequential` block of the JSON line is the same K steps with one
+pair at a time, and `roofline` describes the solve kernel running alone.
+N > 1 ("weak" scaling): one process per GPU; rank 0's deformed frames are broadcast over
+RCCL/xGMI a round of P steps at a time (double-buffered: round m+1 travels while round m is
+solved), each rank correlates its own 10 000-sector grid (the C2 grid shifted by `rank` pixels -
+a denser measurement grid on the same pair) and the records of a round are all-gathered in one
+collective (asynchronously, double-buffered).  value = point-iterations of ALL ranks /
+max-over-ranks time.
 
 Prints ONE JSON line (rank 0).
 """
