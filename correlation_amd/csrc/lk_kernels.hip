@@ -416,9 +416,10 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
         }
       }
       const unsigned long long badmask = __ballot(bad);
+      // Lanes without a sample (j >= n, or a sample that left the image) hold t = +0, and a sum
+      // that started at +0 is never -0, so adding their +0 changes no bit: no select needed.
 #pragma unroll
       for (int j = 0; j < 2 * P; ++j) {
-        const bool take = j < c.n;
 #pragma unroll
         for (int v = 0; v < SumsT::N; ++v) {
           float tj;
@@ -436,8 +437,7 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
           case 10: tj = dpp_bcast<10>(t[v]); break;
           default: tj = dpp_bcast<11>(t[v]); break;
           }
-          const float sum = S.v[v] + tj;
-          S.v[v] = take ? sum : S.v[v];
+          S.v[v] = S.v[v] + tj;
         }
       }
       const int row = ((int)threadIdx.x & 63) >> 4;
