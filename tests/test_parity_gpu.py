@@ -998,6 +998,53 @@ def test_device_rebuilt_lists_equal_the_host_rebuild(monkeypatch, given_centers,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("deformation", [1, 0])
+def test_stop_frame_policy_through_the_frame_loop(oracle, deformation):
+    """stopFrame with sectors that walk out of the image: the sector loop of a frame ends at the
+    first failing sector, the sectors behind it keep the state AND the sample lists they had
+    (lk_restore_sectors after lk_translate_sectors / lk_rewarp_sectors), and the sequence goes on
+    (manager_class.cpp:520-546).  Compared with the manager oracle, which applies the same policy."""
+    from correlation_amd import tracker as tk
+    from oracle import lk_manager_oracle as mo
+    model = ca.FM_UV
+    frames = ca.speckle.speckle_sequence(256, 256, 6, velocity=(3.6, -2.2), dilation=0.0, seed=3)
+    names = [f"f{i}" for i in range(len(frames))]
+    guess = [3.0, -2.0, 0.0, 0.0, 0.0, 0.0]
+    e = ca.HipCorrelationEngine(fitting_model=model)
+    t = tk.SequenceTracker(model, tk.DOMAIN_RECT, deformation, tk.REF_PREVIOUS, tk.ERRMODE_STOP_FRAME, guess, lib=e.lib)
+    o = oracle.Oracle(model=model)
+    o.set_image(0, frames[0])
+    o.set_image(1, frames[1])
+    m = mo.ManagerOracle(o, model, tk.DOMAIN_RECT, deformation, tk.REF_PREVIOUS, mo.ERRMODE_STOP_FRAME, guess)
+    args = (150.0, 20.0, 243.0, 120.0, 196.0, 70.0, 3, 3)      # close to the right and upper borders
+    t.set_rect_domain(*args), m.set_rect_domain(*args)
+    assert tk.run_sequence(e, t, frames, names) == len(frames) - 1
+    for k in range(len(frames) - 1):
+        if k > 0:
+            o.und_from_def()
+            o.set_image(2, frames[k + 1])
+            o.def_from_nxt()
+        m.run_frame(k, names[k], names[k + 1])
+    head_g, got = _report_table(t.report())
+    head_w, want = _report_table(m.report_text())
+    assert head_g == head_w and len(got) == len(want)
+    col = {name: i for i, name in enumerate(head_g)}
+    errors = 0
+    for rg, rw in zip(got, want):
+        for name in ("Frame#", "number_of_points", "error_status", "error_code"):
+            assert rg[col[name]] == rw[col[name]], (rg[0], name, rg[col[name]], rw[col[name]])
+        errors += rg[col["error_status"]] == "1"
+        if rg[col["error_status"]] == "0":   # (a failed sector reports the reference's stale count, DESIGN section 1)
+            assert abs(int(rg[col["iterations"]]) - int(rw[col["iterations"]])) <= 1
+        for name in ("und_center_x", "und_center_y", "def_center_x", "def_center_y", "parameter_0", "parameter_1",
+                     "Initial_guess_0", "Initial_guess_1"):
+            a, b = float(rg[col[name]]), float(rw[col[name]])
+            assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 2e-2, (rg[0], name, a, b)
+    assert errors > 0, "the domain was meant to lose sectors at the border"
+    e.close(), t.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("model,reference", [(ca.FM_UVUXUYVXVY, 0), (ca.FM_UVQ, 0), (ca.FM_UV, 1), (ca.FM_U, 0),
                                              (ca.FM_UVUXUYVXVY, 1)])
 def test_overlapped_frame_loop_equals_the_synchronous_one(monkeypatch, model, reference):
