@@ -140,11 +140,9 @@ def other_configs(ca):
         e.set_deformed_image(dfm)
         rs, as_, ri, ro = 8, 32, 600.0, 1800.0
         dr, da = np.float32((ro - ri) / rs), np.float32(2 * np.pi) / np.float32(as_)
-        s = 0
-        for i in range(rs):
-            for j in range(as_):
-                e.resetPolygon_annular(s, np.float32(ri + i * dr), dr, np.float32(j) * da, da, 2048.0, 2048.0, as_)
-                s += 1
+        e.set_sectors_annular(0, np.float32([[np.float32(ri + i * dr), dr, np.float32(j) * da, da, 2048.0, 2048.0]
+                                             for i in range(rs) for j in range(as_)]), as_)
+        s = rs * as_
         t = 2 * np.pi * np.arange(64) / 64
         rad = np.where(np.arange(64) % 2 == 0, 1500.0, 900.0)
         e.resetPolygon_blob(s, np.stack([2048 + rad * np.cos(t), 2048 + rad * np.sin(t)], 1).astype(np.float32))
