@@ -8,16 +8,17 @@ achieved algorithmic HBM GB/s on the 2048^2 speckle pair of config C2.
 One "step" = one pass of the hot path over one image pair whose level-0 pixels are already
 resident in HBM: build both image pyramids (und, def), solve every sector of the ROI grid
 coarse-to-fine on the device, leave the 48-byte result records in HBM.
-Steps are independent pairs: --inflight P (default 3) keeps P of them on the GPU at once, step
-k on engine k % P, each engine on its own HIP stream - the straggler tail of one solve is filled
-by the next pair's solve.  The `sequential` block of the JSON line is the same K steps with one
-pair at a time, and `roofline` describes the solve kernel running alone.
+`value` / `ms_per_step` are measured ONE PAIR AT A TIME (--inflight 1, the default): the rate a
+tracked sequence gets, and the run whose dominant kernel `roofline` describes - same engine, same
+template instance, same launches.  Independent pairs can overlap (--inflight P: step k on engine
+k % P, each engine on its own HIP stream, the straggler tail of one solve filled by the next
+pair's); that throughput is reported in the `overlapped` block at N = 1, never as `value`.
 N > 1 ("weak" scaling): one process per GPU; rank 0's deformed frames are broadcast over
-RCCL/xGMI a round of P steps at a time (double-buffered: round m+1 travels while round m is
-solved), each rank correlates its own 10 000-sector grid (the C2 grid shifted by `rank` pixels -
-a denser measurement grid on the same pair) and the records of a round are all-gathered in one
-collective (asynchronously, double-buffered).  value = point-iterations of ALL ranks /
-max-over-ranks time.
+RCCL/xGMI a round of --round steps at a time (double-buffered: round m+1 travels while round m
+is solved, the way the reference prefetches the next frame, manager_class.cpp:1438-1447), each
+rank correlates its own 10 000-sector grid (the C2 grid shifted by `rank` pixels - a denser
+measurement grid on the same pair) and the records of a round are all-gathered in one collective
+(asynchronously, double-buffered).  value = point-iterations of ALL ranks / max-over-ranks time.
 
 Prints ONE JSON line (rank 0).
 """
@@ -93,7 +94,8 @@ def other_configs(ca):
         c = wl.size / 2.0
         ok = r["error_code"] == 0
         u_true = truth[0] + truth[2] * (r["und_cx"] - c) + truth[3] * (r["und_cy"] - c)
-        m["median_abs_u_minus_truth"] = float(np.median(np.abs(r["p"][:, 0] - u_true)[ok]))
+        m["median_abs_u_minus_truth"] = float(np.nanmedian(np.abs(r["p"][:, 0] - u_true)[ok]))
+        m["nan_records"] = int(np.isnan(r["p"]).any(1).sum())   # singular starved levels: the reference's QR returns NaN too
         m["workload"] = wl.name
         e.close()
         return m
@@ -102,7 +104,7 @@ def other_configs(ca):
         from correlation_amd.workload import C2, C4, C4B, C5, shard_range
         und, dfm = ca.speckle.speckle_pair(C2.size, C2.size, p=C2.truth, seed=7)
         res = {}
-        for label, interp in (("reference_order", ca.IM_BICUBIC), ("separable", ca.IM_BICUBIC_SEPARABLE)):
+        for label, interp in (("reference_bicubic", ca.IM_BICUBIC), ("separable", ca.IM_BICUBIC_SEPARABLE)):
             e = ca.HipCorrelationEngine(fitting_model=C2.model, py_stop=C2.py_stop, interpolation=interp)
             e.set_undeformed_image(und)
             e.set_deformed_image(dfm)
@@ -111,11 +113,11 @@ def other_configs(ca):
             r, m = timed(e, 10)
             res[label] = (r, m)
             e.close()
-        a, b = res["separable"][0], res["reference_order"][0]
+        a, b = res["separable"][0], res["reference_bicubic"][0]
         m = res["separable"][1]
-        m["solve_ms_reference_order"] = res["reference_order"][1]["solve_ms"]
-        m["max_abs_dp01_vs_reference_order"] = float(np.abs(a["p"] - b["p"])[:, :2].max())
-        m["max_rel_dchi_vs_reference_order"] = float((np.abs(a["chi"] - b["chi"]) / b["chi"]).max())
+        m["solve_ms_reference_bicubic"] = res["reference_bicubic"][1]["solve_ms"]
+        m["max_abs_dp01_vs_reference_bicubic"] = float(np.abs(a["p"] - b["p"])[:, :2].max())
+        m["max_rel_dchi_vs_reference_bicubic"] = float((np.abs(a["chi"] - b["chi"]) / b["chi"]).max())
         m["workload"] = "C2 with LK_IM_BICUBIC_SEPARABLE (extension, not the headline)"
         out["C2_separable_bicubic"] = m
     except Exception as ex:
@@ -149,7 +151,8 @@ def other_configs(ca):
         e.commit_sectors()
         r, m = timed(e)
         u_true = truth[0] + truth[2] * (r["und_cx"] - 2048) + truth[3] * (r["und_cy"] - 2048)
-        m["max_abs_u_minus_truth"] = float(np.abs(r["p"][:, 0] - u_true).max())
+        m["max_abs_u_minus_truth"] = float(np.nanmax(np.abs(r["p"][:, 0] - u_true)))
+        m["nan_records"] = int(np.isnan(r["p"]).any(1).sum())
         m["largest_sector_samples"] = int(r["n_points"].max())
         m["workload"] = "C3: 4096x4096, 8x32 annular sectors + one 64-vertex blob, affine, pyramid 0/1/2"
         out["C3"] = m
@@ -167,14 +170,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sectors", type=int, default=10000)
     ap.add_argument("--no-other-configs", action="store_true")
-    ap.add_argument("--inflight", type=int, default=3,
-                    help="image pairs in flight per GPU: step k runs on engine k %% INFLIGHT, each engine on its own "
-                         "HIP stream, so the straggler tail of one solve is filled by the next pair's solve "
-                         "(1: strictly one pair at a time - the 'sequential' block of the default output)")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="image pairs in flight per GPU in the TIMED region (default 1: one pair at a time, the rate "
+                         "of a tracked sequence and the run `roofline` describes).  P > 1: step k runs on engine "
+                         "k %% P, each on its own HIP stream")
+    ap.add_argument("--round", type=int, default=3,
+                    help="N > 1: steps whose frames travel in one broadcast and whose records leave in one "
+                         "all-gather (the host cost of a collective exceeds a step's GPU time)")
+    ap.add_argument("--overlap", type=int, default=3,
+                    help="N = 1: pairs in flight of the extra `overlapped` block (0: skip it)")
     ap.add_argument("--workload", default="C2", choices=["C2", "C4", "C4B", "C5"],
                     help="C2 (default, the headline: weak scaling, every rank its own 10k-sector grid); "
                          "C4 / C4B / C5: ONE pair of that config with its sector grid sharded over the ranks "
-                         "(strong scaling; frame broadcast + record all-gather per step)")
+                         "(strong scaling; frame broadcast + record all-gather per round)")
     args = ap.parse_args()
 
     import torch
@@ -207,9 +215,11 @@ def main():
     d_und = torch.from_numpy(und).to(dev)
     d_def = torch.from_numpy(dfm).to(dev) if rank == 0 else torch.empty_like(d_und)
 
-    P = max(1, args.inflight)
+    P = max(1, args.inflight)                     # engines (pairs in flight) of the timed region
+    R = max(1, args.round) if use_dist else P     # steps per round of collectives
+    R = ((R + P - 1) // P) * P
 
-    def make_engine(pairs_in_flight):
+    def make_engine(pairs_in_flight, reference_order=0):
         # a dedicated (non-null) HIP stream shared by torch, RCCL and the engine: torch events
         # recorded on it bracket exactly the engine's launches
         eng = ca.HipCorrelationEngine(interpolation=ca.IM_BICUBIC, fitting_model=wl.model, py_stop=wl.py_stop,
@@ -218,6 +228,7 @@ def main():
         assert st_.cuda_stream != 0
         eng.set_stream(st_.cuda_stream)
         eng.set_pairs_in_flight(pairs_in_flight)
+        eng.set_reference_order(reference_order)
         if strong:   # one grid, contiguous blocks of the sector index per rank
             first, count = shard_range(wl.hs * wl.vs, rank, world)
             eng.set_rect_grid(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, wl.hs, wl.vs, first, count)
@@ -228,23 +239,23 @@ def main():
         eng.set_timing(False)   # the engine's own per-call HIP events stay out of the timed frames
         return eng, st_
 
-    # one engine per pair in flight; `e` (one pair at a time) measures the single launch
-    lanes = [make_engine(P) for _ in range(P)]
-    e, stream = make_engine(1) if P > 1 else lanes[0]
+    engines = [make_engine(P) for _ in range(P)]
+    lanes = [engines[j % P] for j in range(R)]    # lane j of a round -> (engine, stream)
+    e, stream = engines[0]
     S = e.n_sectors
     S_cap = (wl.hs * wl.vs + world - 1) // world if strong else S   # equal all-gather blocks
     n0 = e.sector_info(0)[0]
     d_guess = torch.zeros((S, 6), dtype=torch.float32, device=dev)
-    # Steps are dealt to the lanes in rounds of P.  The P frames of round m+1 travel in ONE
-    # broadcast while round m is being solved, and the P record blocks of round m leave in ONE
+    # Steps are dealt to the lanes in rounds of R.  The R frames of round m+1 travel in ONE
+    # broadcast while round m is being solved, and the R record blocks of round m leave in ONE
     # all-gather once its solves are done (the reference prefetches the next frame the same
     # way, manager_class.cpp:1438-1447): two collectives per round keep the host out of the way
     # (one broadcast and one gather per step cost ~0.2 ms of host time per step - more than a
     # step takes on the GPU).  Two sets of buffers alternate between rounds.
-    d_defs = [torch.stack([d_def] * P) for _ in range(2)]                       # [2][P, H, W]
-    d_ress = [torch.zeros((P, S_cap, 48), dtype=torch.uint8, device=dev) for _ in range(2)]
-    d_alls = [torch.empty((world, P, S_cap, 48), dtype=torch.uint8, device=dev) for _ in range(2)] if use_dist else None
-    solved = [torch.cuda.Event() for _ in range(P)]     # lane j's latest solve
+    d_defs = [torch.stack([d_def] * R) for _ in range(2)]                       # [2][R, H, W]
+    d_ress = [torch.zeros((R, S_cap, 48), dtype=torch.uint8, device=dev) for _ in range(2)]
+    d_alls = [torch.empty((world, R, S_cap, 48), dtype=torch.uint8, device=dev) for _ in range(2)] if use_dist else None
+    solved = [torch.cuda.Event() for _ in range(R)]     # lane j's latest solve
     pending = {"bcast": [None, None], "gather": [None, None], "k": 0}
 
     def after_all_lanes(st_):   # st_ continues after the latest solve of every lane
@@ -262,7 +273,7 @@ def main():
 
     def step():
         k = pending["k"]
-        m, j = divmod(k, P)
+        m, j = divmod(k, R)
         eng, st_ = lanes[j]
         torch.cuda.set_stream(st_)   # RCCL orders its work against torch's current stream: the lane's own
         if use_dist:
@@ -277,14 +288,14 @@ def main():
         eng.correlate_all_device(d_guess.data_ptr(), d_ress[m % 2][j].data_ptr())     # the solve
         if use_dist:
             solved[j].record(st_)
-            if j == P - 1:
+            if j == R - 1:
                 after_all_lanes(st_)
                 pending["gather"][m % 2] = gather(m)
         pending["k"] = k + 1
 
     def fence():
         if use_dist:
-            m, j = divmod(pending["k"], P)
+            m, j = divmod(pending["k"], R)
             if j != 0:                                   # a round cut short by the end of the timed region
                 st_ = lanes[j - 1][1]
                 torch.cuda.set_stream(st_)
@@ -304,36 +315,13 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    m_last, j_last = divmod(pending["k"] - 1, P)
+    m_last, j_last = divmod(pending["k"] - 1, R)
     res = d_ress[m_last % 2][j_last][:S].cpu().numpy().view(ca.RESULT_DTYPE).reshape(-1)   # the last timed step's records
-    eng0 = lanes[0][0]
-    eng0.set_timing(True)
-    eng0.set_image_device(ca.IMG_DEF, d_defs[0][0].data_ptr(), wl.size, wl.size)
-    eng0.correlate_all_device(d_guess.data_ptr(), d_ress[0][0].data_ptr())   # untimed: fills lk_stats
-    torch.cuda.synchronize(dev)
-    st_lanes = eng0.stats()   # counters of one solve of the engines the timed region ran on
 
-    # one pair at a time on `e`: the same step, strictly sequential, and the single launch
+    # The dominant kernel of the SAME engine on the SAME stream: per-launch duration measured live
+    # with HIP events around K back-to-back solve launches (no pyramid launches in between), then
+    # one untimed solve with the engine's own events on to fill lk_stats.
     torch.cuda.set_stream(stream)
-
-    def seq_step():
-        e.set_image_pair_device(d_und.data_ptr(), d_defs[0][0].data_ptr(), wl.size, wl.size)
-        e.correlate_all_device(d_guess.data_ptr(), d_ress[0][0].data_ptr())
-
-    for _ in range(min(args.warmup, 10)):
-        seq_step()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        seq_step()
-    torch.cuda.synchronize(dev)
-    dt_seq = time.perf_counter() - t0
-    e.set_timing(True)
-    e.set_image_device(ca.IMG_DEF, d_defs[0][0].data_ptr(), wl.size, wl.size)
-    e.correlate_all_device(d_guess.data_ptr(), d_ress[0][0].data_ptr())   # untimed: fills lk_stats' event times
-    st = e.stats()   # counters + the engine's own HIP-event time of the LAST solve launch
-    # per-launch duration of the dominant kernel running alone, measured live with HIP events on
-    # the stream it runs on: K back-to-back solve launches bracketed by two events
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
     for _ in range(args.steps):
@@ -341,33 +329,100 @@ def main():
     e1.record(stream)
     torch.cuda.synchronize(dev)
     solve_avg_ms = e0.elapsed_time(e1) / args.steps
-    # ... and with P pairs in flight: K solve launches dealt to the lanes, first start to last end
-    torch.cuda.set_stream(lanes[0][1])
+    e.set_timing(True)
+    e.set_image_device(ca.IMG_DEF, d_defs[0][0].data_ptr(), wl.size, wl.size)
+    e.correlate_all_device(d_guess.data_ptr(), d_ress[0][0].data_ptr())
     torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        lanes[k % P][0].correlate_all_device(d_guess.data_ptr(), d_ress[(k // P) % 2][k % P].data_ptr())
-    torch.cuda.synchronize(dev)
-    solve_overlapped_ms = (time.perf_counter() - t0) / args.steps * 1e3
+    st = e.stats()   # counters + the engine's own HIP-event time of the LAST solve
+    e.set_timing(False)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    pit = torch.tensor([float(st_lanes["point_iterations"])], dtype=torch.float64, device=dev)
+    pit = torch.tensor([float(st["point_iterations"])], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(pit, op=dist.ReduceOp.SUM)
     dt_max = float(tmax.item())
     total_pit = float(pit.item()) * args.steps
 
+    # ---- extra blocks at N = 1 (never part of `value`) ----------------------------------------
+    overlapped = None
+    if world == 1 and not use_dist and args.overlap > 1 and P == 1:
+        Q = args.overlap
+        extra = [make_engine(Q) for _ in range(Q)]
+        d_r = [torch.zeros((S, 48), dtype=torch.uint8, device=dev) for _ in range(Q)]
+
+        def ostep(k):
+            eng, st_ = extra[k % Q]
+            eng.set_image_pair_device(d_und.data_ptr(), d_def.data_ptr(), wl.size, wl.size)
+            eng.correlate_all_device(d_guess.data_ptr(), d_r[k % Q].data_ptr())
+
+        for k in range(min(args.warmup, 3 * Q)):
+            ostep(k)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            ostep(k)
+        torch.cuda.synchronize(dev)
+        dt_o = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for k in range(args.steps):   # solves only
+            extra[k % Q][0].correlate_all_device(d_guess.data_ptr(), d_r[k % Q].data_ptr())
+        torch.cuda.synchronize(dev)
+        ms_o = (time.perf_counter() - t0) / args.steps * 1e3
+        extra[0][0].set_timing(True)
+        extra[0][0].correlate_all_device(d_guess.data_ptr(), d_r[0].data_ptr())
+        torch.cuda.synchronize(dev)
+        st_o = extra[0][0].stats()
+        overlapped = {"pairs_in_flight": Q, "value": float(st_o["point_iterations"]) * args.steps / dt_o,
+                      "ms_per_step": 1e3 * dt_o / args.steps, "solve_ms_per_launch": ms_o,
+                      "algorithmic_GBps": st_o["algorithmic_bytes"] / (ms_o * 1e-3) / 1e9,
+                      "frac_of_hbm_peak": st_o["algorithmic_bytes"] / (ms_o * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "note": f"{Q} independent pairs in flight, one engine and HIP stream each (16-lane groups); a tracked "
+                              "sequence cannot do this (pair k+1 starts from pair k's result)"}
+        for eng, _ in extra:
+            eng.close()
+
+    ref_order = None
+    res_ref = None
+    if world == 1 and not use_dist and not strong:
+        er, st_r = make_engine(1, reference_order=1)
+        torch.cuda.set_stream(st_r)
+        d_rr = torch.zeros((S, 48), dtype=torch.uint8, device=dev)
+        er.set_image_pair_device(d_und.data_ptr(), d_def.data_ptr(), wl.size, wl.size)
+        for _ in range(3):
+            er.correlate_all_device(d_guess.data_ptr(), d_rr.data_ptr())
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_r = max(10, args.steps // 4)
+        r0.record(st_r)
+        for _ in range(n_r):
+            er.correlate_all_device(d_guess.data_ptr(), d_rr.data_ptr())
+        r1.record(st_r)
+        torch.cuda.synchronize(dev)
+        ms_r = r0.elapsed_time(r1) / n_r
+        res_ref = d_rr.cpu().numpy().view(ca.RESULT_DTYPE).reshape(-1)
+        st_rr = er.stats()
+        ref_order = {"solve_ms": ms_r, "point_iterations_per_s": st_rr["point_iterations"] / (ms_r * 1e-3),
+                     "algorithmic_GBps": st_rr["algorithmic_bytes"] / (ms_r * 1e-3) / 1e9,
+                     "note": "lk_set_reference_order(1): ordered sums + the restated QR at every level; records "
+                             "bit-identical to the CPU oracle (see parity_vs_cpu)"}
+        er.close()
+        torch.cuda.set_stream(stream)
+
     if rank == 0:
         value = total_pit / dt_max
         achieved = st["algorithmic_bytes"] / (solve_avg_ms * 1e-3) / 1e9
-        # HBM bytes per solve launch from the PMC passes of this workload (FETCH_SIZE +
-        # WRITE_SIZE, calibrated; profiles/r01_pmc_traffic.txt) - a profile, not a live counter
-        traffic = None
+        # HBM bytes per solve launch: a PROFILE CONSTANT from the PMC passes of this workload
+        # (FETCH_SIZE + WRITE_SIZE, corrected; profiles/*_pmc_traffic.txt), not a counter read in this run
+        traffic, traffic_src = None, None
         try:
             if not strong:   # the PMC profile is of the C2 launch
-                with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-                    traffic = json.load(f)["solve_kernel_hbm_bytes_per_launch_C2"] / (solve_avg_ms * 1e-3) / 1e9
+                for name in ("r02_traffic.json", "r01_traffic.json"):
+                    path = os.path.join(ROOT, "profiles", name)
+                    if os.path.exists(path):
+                        with open(path) as f:
+                            traffic = json.load(f)["solve_kernel_hbm_bytes_per_launch_C2"]
+                        traffic_src = f"profile constant: profiles/{name} (rocprofv3 --pmc passes), bytes per launch"
+                        break
         except Exception:
             pass
         line = {
@@ -387,36 +442,33 @@ def main():
                        "samples_per_sector": n0,
                        "interpolation": "bicubic", "parallelism": f"sectors sharded x{world}",
                        "pairs_in_flight": P,
-                       "step": "pyramid(und)+pyramid(def)+solve of one pair, inputs resident in HBM; step k runs on "
-                               f"engine k % {P} (own HIP stream), so up to {P} independent pairs overlap on the GPU"},
-            # the same step with one pair at a time (bench.py --inflight 1): the latency of a pair
-            "sequential": {"pairs_in_flight": 1, "value": float(st["point_iterations"]) * args.steps / dt_seq,
-                           "ms_per_step": 1e3 * dt_seq / args.steps},
+                       "step": "pyramid(und)+pyramid(def)+solve of one pair, inputs resident in HBM, "
+                               + ("one pair at a time" if P == 1 else f"up to {P} independent pairs overlap on the GPU")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("lk_solve_kernel<fm_UVUxUyVxVy, im_bicubic> (32-lane groups, 2 sectors per wavefront; the events "
-                                    "also bracket the SAFE pass for ill-conditioned sectors, an empty 4 us launch here)"
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": ("lk_solve_kernel<fm_UVUxUyVxVy, im_bicubic> of the engine that produced `value` (the events "
+                                    "also bracket the SAFE pass for ill-conditioned sectors, an empty launch here)"
                                     if not strong else
-                                    "lk_solve_kernel<fm_UVUxUyVxVy, im_bicubic>: all launches of one solve "
-                                    "(one-lane starved-level kernel, finisher, 16-lane groups)"),
+                                    "lk_solve_kernel<fm_UVUxUyVxVy, im_bicubic>: all launches of one solve"),
                          "kernel_ms": solve_avg_ms,
-                         "measured": "the kernel running alone: K back-to-back launches of one engine between two HIP "
-                                     "events on its stream (rocprofv3 of `bench.py --inflight 1` agrees)",
-                         "algorithmic_bytes_per_launch": st["algorithmic_bytes"],
-                         # K launches dealt to the P engines: (last end - first start) / K
-                         "with_pairs_in_flight": {"pairs": P, "ms_per_launch": solve_overlapped_ms,
-                                                  "achieved": st_lanes["algorithmic_bytes"] / (solve_overlapped_ms * 1e-3) / 1e9,
-                                                  "frac": st_lanes["algorithmic_bytes"] / (solve_overlapped_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+                         "measured": "K back-to-back solve launches of the engine and stream the timed region ran on, "
+                                     "between two HIP events on that stream",
+                         "algorithmic_bytes_per_launch": st["algorithmic_bytes"]},
             "per_pair": {"sectors_per_s": (wl.hs * wl.vs if strong else S * world) * args.steps / dt_max,
-                         "evaluations": st_lanes["evaluations"], "sample_evaluations": st_lanes["sample_evaluations"],
-                         "point_iterations": st_lanes["point_iterations"],
-                         "mean_point_iterations_per_sector": st_lanes["point_iterations"] / S,
+                         "evaluations": st["evaluations"], "sample_evaluations": st["sample_evaluations"],
+                         "point_iterations": st["point_iterations"],
+                         "mean_point_iterations_per_sector": st["point_iterations"] / S,
                          "error_free_fraction": float((res["error_code"] == 0).mean()),
+                         "nan_records": int(np.isnan(res["p"]).any(1).sum()),
                          "last_solve_ms": st["solve_ms"], "last_pyramid_ms": st["pyramid_ms"]},
         }
+        if overlapped:
+            line["overlapped"] = overlapped
+        if ref_order:
+            line["reference_order_mode"] = ref_order
         if world == 1 and not args.no_cpu_baseline and not strong:
             base, nsec = cpu_baseline(wl, und, dfm, args.cpu_sectors)
-            pit_per_sector = st_lanes["point_iterations"] / S
+            pit_per_sector = st["point_iterations"] / S
             rate_mt, dt_mt, thr_mt, res_mt = base["all_cores"]
             rate_1, dt_1, _, res_1 = base["1_thread"]
             line["cpu_baseline"] = {
@@ -430,16 +482,23 @@ def main():
             xs = np.linspace(0, S - 1, min(args.cpu_sectors, S)).astype(np.int64)
             line["parity_vs_cpu"] = {
                 "sectors": int(len(xs)),
-                "max_abs_dp01": float(np.abs(res["p"][xs][:, :2] - res_1["p"][:, :2]).max()),
-                "max_rel_dchi": float((np.abs(res["chi"][xs] - res_1["chi"]) / np.abs(res_1["chi"])).max()),
-                "iterations_equal_fraction": float((res["iterations"][xs] == res_1["iterations"]).mean()),
+                "fast_mode": {
+                    "max_abs_dp01": float(np.abs(res["p"][xs][:, :2] - res_1["p"][:, :2]).max()),
+                    "max_rel_dchi": float((np.abs(res["chi"][xs] - res_1["chi"]) / np.abs(res_1["chi"])).max()),
+                    "iterations_equal_fraction": float((res["iterations"][xs] == res_1["iterations"]).mean())},
             }
+            if res_ref is not None:
+                same = np.array([res_ref[i].tobytes() == res_1[j].tobytes() for j, i in enumerate(xs)])
+                line["parity_vs_cpu"]["reference_order_mode"] = {
+                    "records_bit_identical": int(same.sum()), "of": int(len(xs)),
+                    "max_rel_dchi": float((np.abs(res_ref["chi"][xs] - res_1["chi"]) / np.abs(res_1["chi"])).max())}
         if world == 1 and not args.no_other_configs and not use_dist and not strong:
-            for eng in {id(x): x for x in [e] + [l[0] for l in lanes]}.values():
+            for eng in {id(x[0]): x[0] for x in engines}.values():
                 eng.close()
+            engines = []
             line["other_configs"] = other_configs(ca)
         print(json.dumps(line))
-    for eng in {id(x): x for x in [e] + [l[0] for l in lanes]}.values():
+    for eng in {id(x[0]): x[0] for x in engines}.values():
         eng.close()
     if use_dist:
         dist.destroy_process_group()

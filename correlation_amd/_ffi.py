@@ -58,6 +58,7 @@ SYMBOLS = {
     "lk_set_stream": (C.c_int, [_P, _P]),
     "lk_set_timing": (C.c_int, [_P, C.c_int]),
     "lk_set_batch_invariant": (C.c_int, [_P, C.c_int]),
+    "lk_set_reference_order": (C.c_int, [_P, C.c_int]),
     "lk_set_pairs_in_flight": (C.c_int, [_P, C.c_int]),
     "lk_synchronize": (C.c_int, [_P]),
     "lk_set_image": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int]),

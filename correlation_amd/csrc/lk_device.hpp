@@ -66,6 +66,8 @@ struct LkSolveArgs {
   int align;             // 1: the sectors of a wavefront (16/32-lane groups) descend the pyramid together
   int solo;              // 1: an idle half-wavefront may join its partner's sector (32-lane groups)
   int safe;              // 1: reference-exact handling of starved / ill-conditioned levels
+  int reference_order;   // T > 0 (SAFE 16- / 64-lane kernels): every level with the reference's summation order for
+                         //   number_of_threads = T and its QR - bit-identical records (lk_set_reference_order)
   int persistent;        // 1: groups pull sectors from `queue`; 0: one sector per group by position
   int gpu_share;         // launches that may hold the GPU at the same time (>= 1): bounds a team launch's width
   int py_start, py_step, py_stop;
@@ -92,4 +94,5 @@ struct LkEvalArgs { // stand-alone evaluation (known-answer tests)
   int sector, level;
   float p[6];
   float *out; // [36 + 6 + 1 + 1]: A row-major 6x6 (upper), b, chi, error
+  int ref_threads; // > 0: the reference's summation order for number_of_threads = ref_threads (evaluate_ordered)
 };

@@ -43,6 +43,7 @@ int lk_decimate_tiles(uint32_t n_max);
 hipError_t lk_launch_decimate(const float2 *xy_prev, const uint32_t *off_prev, const uint32_t *n_prev, uint32_t n_max,
                               int level_delta, int n_sectors, uint32_t *pos, uint32_t *tiles, float2 *xy_out,
                               uint32_t *off_out, uint32_t *n_out, hipStream_t st);
+hipError_t lk_launch_stale_iterations(lk_result *r, int n, const int *carry_in, int *carry_out, hipStream_t st);
 hipError_t lk_launch_mean_center(const float2 *xy, const uint32_t *off, int n_sectors, float2 *center, hipStream_t st);
 
 namespace {
@@ -138,6 +139,9 @@ struct lk_engine {
   hipEvent_t ev_fork = nullptr, ev_join[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool nxt_pending = false, solve_timed = false, pyr_timed = false;
   bool batch_invariant = false; // lk_set_batch_invariant
+  DevBuf<int> d_stale;          // reference-order mode: reached_iterations as the last solved sector left it ([2], alternating)
+  int stale_par = 0;
+  int reference_order = 0;      // lk_set_reference_order: 0 = off, T = the reference's number_of_threads to reproduce
   int pairs_in_flight = 1;      // lk_set_pairs_in_flight: launches that share the GPU
   bool timing = true; // HIP events around pyramid builds and solves (lk_stats.solve_ms / pyramid_ms)
   std::mutex nxt_mu;
@@ -290,6 +294,7 @@ void lk_destroy(lk_engine *e) {
   e->d_ill_list.release();
   e->d_ill_count.release();
   e->d_scratch.release();
+  e->d_stale.release();
   e->d_warp.release();
   e->d_team_partials.release();
   e->d_team_arrivals.release();
@@ -337,6 +342,17 @@ int lk_set_batch_invariant(lk_engine *e, int enabled) {
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
   e->batch_invariant = enabled != 0;
+  return LK_ERROR_NONE;
+}
+
+int lk_set_reference_order(lk_engine *e, int threads) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (threads < 0 || threads > 4096)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_reference_order: threads must be in 0..4096");
+  if ((threads > 0) != (e->reference_order > 0) && e->committed)
+    e->recommit_pending = true; // the lane groups depend on the mode (commit_impl)
+  e->reference_order = threads;
   return LK_ERROR_NONE;
 }
 
@@ -907,7 +923,7 @@ static int commit_impl(lk_engine *e, bool keep_state) {
     tot[c] += (size_t)n0;
   }
   for (int c = 0; c + 1 < kTeamClass; ++c) { // (nothing is promoted into the team class)
-    if (!cnt[c] || e->batch_invariant) // batch-invariant records: the group depends on the sector alone
+    if (!cnt[c] || e->batch_invariant || e->reference_order > 0) // (the group depends on the sector alone)
       continue;
     // Wider groups shorten a sector's own critical path and cost lane packing: they pay only
     // while the narrow grouping leaves SIMDs without a wavefront (fewer wavefronts than the
@@ -948,7 +964,7 @@ static int commit_impl(lk_engine *e, bool keep_state) {
     int n_big = 0;
     for (int s = 0; s < S; ++s)
       n_big += e->h_class[(size_t)s] >= kTeamClass - 1;
-    if (n_big > 0 && n_big <= kFewBigSectors && !e->batch_invariant)
+    if (n_big > 0 && n_big <= kFewBigSectors && !e->batch_invariant && e->reference_order == 0)
       for (int s = 0; s < S; ++s)
         if (e->h_class[(size_t)s] == kTeamClass - 1)
           e->h_class[(size_t)s] = kTeamClass;
@@ -1551,6 +1567,18 @@ static int launch_groups(lk_engine *e, LkSolveArgs &a, int group, int c, int fir
 static std::mutex g_team_mu;
 static hipEvent_t g_team_done[64] = {};
 
+// reference-order mode: records whose first evaluation failed report the iteration count the
+// previously solved sector left behind (lk_stale_iterations_kernel)
+static int stale_iterations(lk_engine *e, lk_result *d_result, int n) {
+  if (!e->d_stale.p) {
+    HIPCHK(e->d_stale.ensure(2));
+    HIPCHK(hipMemsetAsync(e->d_stale.p, 0, 2 * sizeof(int), e->stream));
+  }
+  HIPCHK(lk_launch_stale_iterations(d_result, n, e->d_stale.p + e->stale_par, e->d_stale.p + (e->stale_par ^ 1), e->stream));
+  e->stale_par ^= 1;
+  return LK_ERROR_NONE;
+}
+
 static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
   if (e->timing)
     HIPCHK(hipEventRecord(e->ev_s0, e->stream));
@@ -1585,6 +1613,22 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
     a.n_sectors = n;
     a.queue = e->d_queue.p + 8 * c;
     a.safe = e->force_safe ? 1 : 0;
+    if (e->reference_order > 0) {
+      // Reference-order mode: ONE launch per class, every level with the ordered sums and the
+      // restated QR - a 16-lane row per small sector (four sectors share a wavefront's QR),
+      // a wavefront per larger one.  No starved-level kernel, finisher, SAFE pass or team: the
+      // ordered kernel is all of them.
+      a.safe = 1;
+      a.solo = 0;
+      a.reference_order = e->reference_order;
+      HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, c == 0 ? 16 : 64, st));
+      if (st != e->stream) {
+        HIPCHK(hipEventRecord(e->ev_join[c], st));
+        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join[c], 0));
+      }
+      ++n_launched;
+      continue;
+    }
     std::unique_lock<std::mutex> team_turn;
     hipEvent_t *team_done = nullptr;
     if (c == kTeamClass) {
@@ -1619,6 +1663,11 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
       HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join[c], 0));
     }
     ++n_launched;
+  }
+  if (e->reference_order > 0) {
+    int rc = stale_iterations(e, d_result, e->S);
+    if (rc)
+      return rc;
   }
   if (e->timing) {
     HIPCHK(hipEventRecord(e->ev_s1, e->stream));
@@ -1726,6 +1775,27 @@ int lk_correlate(lk_engine *e, int sector, float *guess_inout, lk_result *out) {
   a.n_sectors = 1;
   a.queue = e->d_queue.p;
   a.safe = e->force_safe ? 1 : 0;
+  if (e->reference_order > 0) { // (see launch_all)
+    a.safe = 1;
+    a.solo = 0;
+    a.reference_order = e->reference_order;
+    if (e->timing)
+      HIPCHK(hipEventRecord(e->ev_s0, e->stream));
+    HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, e->h_class[(size_t)sector] == 0 ? 16 : 64,
+                           e->stream));
+    if (int rc2 = stale_iterations(e, e->d_result.p + sector, 1))
+      return rc2;
+    if (e->timing) {
+      HIPCHK(hipEventRecord(e->ev_s1, e->stream));
+      e->solve_timed = true;
+    }
+    e->stats_valid = false;
+    HIPCHK(hipMemcpyAsync(out, e->d_result.p + sector, sizeof(lk_result), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < e->P; ++i)
+      guess_inout[i] = out->resultingParameters[i];
+    return LK_ERROR_NONE;
+  }
   std::unique_lock<std::mutex> team_turn;
   hipEvent_t *team_done = nullptr;
   if (e->h_class[(size_t)sector] == kTeamClass) {
@@ -1816,8 +1886,10 @@ int lk_evaluate(lk_engine *e, int sector, int level, const float *p, float *A36,
   for (int i = 0; i < 6; ++i)
     a.p[i] = i < e->P ? p[i] : 0.f;
   a.out = e->d_scratch.p;
-  HIPCHK(lk_launch_eval(a, e->cfg.fitting_model, e->cfg.interpolation,
-                        kGroupOfClass[e->h_class[(size_t)sector]], e->stream));
+  a.ref_threads = e->reference_order;
+  const int group = e->reference_order > 0 ? (e->h_class[(size_t)sector] == 0 ? 16 : 64)
+                                           : kGroupOfClass[e->h_class[(size_t)sector]];
+  HIPCHK(lk_launch_eval(a, e->cfg.fitting_model, e->cfg.interpolation, group, e->stream));
   float h[44];
   HIPCHK(hipMemcpyAsync(h, e->d_scratch.p, sizeof(h), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));

@@ -637,6 +637,154 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
 }
 
 // ------------------------------------------------------------------------------------
+// Reference-order evaluation (lk_set_reference_order): A, b and chi with the SAME sequence of
+// roundings as the CPU engine, at any sector size.
+//
+// The reference adds the rounded products of sample 0, 1, 2, ... (x outer / y inner for
+// rectangles, manager_class.cpp:1607-1611) into one running float per sum
+// (interpolation_class.cpp:722-749); with number_of_threads = T it does so per contiguous chunk
+// of n/T samples (the first n%T chunks one longer, correlation_class.cpp:169-186) and adds the
+// chunk sums in thread order into zeroed totals (:253-275).  The additions of one sum are a
+// chain - but the 28 sums are independent chains, and everything before the additions is
+// independent per sample.  So: the GROUP lanes of a lane group take GROUP consecutive samples,
+// form the rounded products (warp, bicubic, residual, H - the expensive 95 %), and transpose
+// them through LDS; then lane v owns sum v and walks the GROUP products of its sum in sample
+// order (16-lane rows: lanes own sums v and v + 16).  Per GROUP samples that is N stores, GROUP/4
+// 128-bit loads and GROUP dependent adds per lane - against ~390 instructions for the samples
+// themselves.  Products of lanes beyond the list are +0: a sum that started at +0 is never -0,
+// so adding +0 changes no bit.  The totals go back to every lane through LDS.
+// ord: this wavefront's staging area, kOrdFloats<N, GROUP> floats.
+// ------------------------------------------------------------------------------------
+template <int GROUP> constexpr int ord_stride() { return GROUP + 4; } // +4: the 128-bit reads of neighbouring lanes hit different banks
+template <int N, int GROUP> constexpr int ord_floats() { return (kWave / GROUP) * N * ord_stride<GROUP>(); }
+
+template <int MODEL, int INTERP, int GROUP>
+__device__ __forceinline__ bool evaluate_ordered(const LevelCtx &c, const float (&p)[6],
+                                                 Sums<n_params(MODEL)> &S, float *ord, int threads) {
+  static_assert(GROUP == 16 || GROUP == 64, "one 16-lane row or one wavefront per sector");
+  constexpr int P = n_params(MODEL);
+  using SumsT = Sums<P>;
+  constexpr int N = SumsT::N, STR = ord_stride<GROUP>();
+  constexpr bool TWO = GROUP == 16 && N > 16; // a 16-lane row owns up to 32 sums: v and v + 16
+  const int lane = (int)threadIdx.x & (kWave - 1), g = lane & (GROUP - 1);
+  float *mine = ord + (lane / GROUP) * (N * STR); // the group's [N][STR] staging block
+  const int v0 = g < N ? g : 0, v1 = (TWO && g + 16 < N) ? g + 16 : 0; // (idle lanes shadow sum 0)
+  float acc0 = 0.f, acc1 = 0.f, tot0 = 0.f, tot1 = 0.f;
+  // thread chunks of the reference: chunk t has n/T + (t < n%T) samples
+  const int T = threads < 1 ? 1 : threads;
+  const int cq = c.n / T, cr = c.n - cq * T;
+  int t_idx = 0, next_b = cq + (cr > 0 ? 1 : 0);
+  bool bad = false;
+  const int umaxr = c.urows - 1, umaxc = c.ucols - 1;
+  const int rh = c.rw > 0 ? c.n / c.rw : 1; // height of the implicit rectangle
+  const float inv_rh = 1.f / (float)rh;
+  for (int base = 0; __any(base < c.n); base += GROUP) {
+    const int k = base + g;
+    float t[N];
+#pragma unroll
+    for (int v = 0; v < N; ++v)
+      t[v] = 0.f;
+    if (k < c.n) {
+      f32x2 q;
+      if (c.rw > 0) { // x outer, y inner: k -> (column, row) of the rectangle
+        int col = (int)((float)k * inv_rh); // within a few units of k / rh; corrected below
+        int row = k - col * rh;
+        while (row < 0) {
+          row += rh;
+          --col;
+        }
+        while (row >= rh) {
+          row -= rh;
+          ++col;
+        }
+        q.x = (float)(c.rx + col);
+        q.y = (float)(c.ry + row);
+      } else {
+        q = c.xy[k];
+      }
+      float xd, yd, dx = 0.f, dy = 0.f;
+      Warp<MODEL>::apply(q.x, q.y, c.cx, c.cy, p, xd, yd, dx, dy);
+      int uix = (int)(q.x + 0.5f), uiy = (int)(q.y + 0.5f);
+      uix = min(max(uix, 0), umaxc);
+      uiy = min(max(uiy, 0), umaxr);
+      const float und_w = (float)c.und[(size_t)uiy * (size_t)c.ucols + (size_t)uix];
+      float W, Wx, Wy;
+      if (!sample_def<INTERP>(c.def, c.drows, c.dcols, xd, yd, W, Wx, Wy)) {
+        bad = true; // (the sums of an evaluation that hit the error are never used)
+      } else {
+        const float V = und_w - W;
+        float H[P];
+        Warp<MODEL>::jac(Wx, Wy, dx, dy, H);
+        int idx = 0;
+#pragma unroll
+        for (int p1 = 0; p1 < P; ++p1)
+#pragma unroll
+          for (int p2 = p1; p2 < P; ++p2)
+            t[idx++] = H[p1] * H[p2]; // rounded product; the rounded add follows below
+#pragma unroll
+        for (int p1 = 0; p1 < P; ++p1)
+          t[SumsT::NA + p1] = H[p1] * V;
+        t[N - 1] = V * V;
+      }
+    }
+    // transpose: lane g's product of sum v -> mine[v][g]  (all lanes of the wavefront take part)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the previous pass's reads are done
+#pragma unroll
+    for (int v = 0; v < N; ++v)
+      mine[v * STR + g] = t[v];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float *r0 = mine + v0 * STR, *r1 = mine + v1 * STR;
+#pragma unroll
+    for (int j4 = 0; j4 < GROUP / 4; ++j4) {
+      const float4 a4 = *reinterpret_cast<const float4 *>(r0 + 4 * j4);
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (TWO)
+        b4 = *reinterpret_cast<const float4 *>(r1 + 4 * j4);
+      const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (T > 1 && base + 4 * j4 + j == next_b) { // a thread chunk ends before this sample (:253-275)
+          tot0 += acc0;
+          acc0 = 0.f;
+          if constexpr (TWO) {
+            tot1 += acc1;
+            acc1 = 0.f;
+          }
+          ++t_idx;
+          next_b += cq + (t_idx < cr ? 1 : 0);
+        }
+        acc0 += av[j];
+        if constexpr (TWO)
+          acc1 += bv[j];
+      }
+    }
+  }
+  tot0 += acc0; // the last chunk (T == 1: 0 + acc)
+  if constexpr (TWO)
+    tot1 += acc1;
+  // totals back to every lane of the group
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  if (g < N)
+    mine[g] = tot0;
+  if constexpr (TWO)
+    if (g + 16 < N)
+      mine[g + 16] = tot1;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int v = 0; v < N; ++v)
+    S.v[v] = mine[v];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (the next evaluation overwrites mine[])
+  const unsigned long long badmask = __ballot(bad);
+  if constexpr (GROUP == 16)
+    return ((badmask >> (16 * (lane >> 4))) & 0xffffull) != 0ull;
+  return badmask != 0ull;
+}
+
+// ------------------------------------------------------------------------------------
 // the damped normal-equation solve (compute_model_parameters + solve,
 // correlation_class.cpp:642-768)
 // ------------------------------------------------------------------------------------
@@ -1168,6 +1316,7 @@ template <int P> __device__ __forceinline__ void translate(float (&p)[6], int sr
 // behind); then one wavefront per 64/GROUP sectors is launched and the hardware dispatcher
 // fills freed slots with whole wavefronts (measured on C2: 0.33 vs 0.37 ms).
 enum : int { PH_EVAL0 = 0, PH_TENT = 1, PH_REEVAL = 2, PH_FETCH = 3, PH_EXIT = 4 };
+constexpr int kStaleIterations = (int)0x80000000; // marker in lk_result.iterations, see lk_stale_iterations_kernel
 
 // Per-sector state that is only touched between evaluations ("cold": last-good parameters,
 // damping, counters, ...).  For the small lane groups it lives in LDS - every lane of a group
@@ -1220,9 +1369,15 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
   constexpr bool STARVED = GROUP == 1; // one lane per sector: solves only the starved top levels
   // the 16-lane SAFE instance doubles as the finisher of that kernel's stragglers (a.finisher)
   const bool finisher = SAFE && GROUP == 16 && a.finisher != 0;
-  const bool starved = STARVED || finisher;
+  // reference-order mode (lk_set_reference_order): the SAFE 16- and 64-lane instances solve every
+  // level with evaluate_ordered + the restated QR - sums, steps and records bit-identical to the
+  // CPU engine with number_of_threads = a.reference_order
+  constexpr bool ORD = SAFE && THREADS == kWave && (GROUP == 16 || GROUP == kWave);
+  const bool ordered_all = ORD && a.reference_order > 0;
+  const bool starved = STARVED || finisher || ordered_all;
   constexpr int RED_WORDS = GROUP > kWave ? (THREADS / kWave) * (SumsT::N + 1) + 1 : 1;
   __shared__ float lds[RED_WORDS];
+  __shared__ __attribute__((aligned(16))) float ord_lds[ORD ? ord_floats<SumsT::N, ORD ? GROUP : 16>() : 4];
   __shared__ uint32_t cold_lds[COLD_IN_LDS ? (THREADS / GROUP) * kColdWords : 1];
   uint32_t *cold_slot = cold_lds + (COLD_IN_LDS ? ((int)threadIdx.x / GROUP) * kColdWords : 0);
   ColdStore<COLD_IN_LDS> cold;
@@ -1349,7 +1504,12 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
       r.chi = k.lg_chi;
       const int4 rc0 = a.lv[0].rect[k.s];
       r.numberOfPoints = rc0.z > 0 ? rc0.w : (int)(a.lv[0].off[k.s + 1] - a.lv[0].off[k.s]);
-      r.iterations = k.reached;
+      // reference-order mode: the very first evaluation of the sector failed, so no LM trip ever ran -
+      // the reference then reports whatever its reached_iterations member still holds from the sector
+      // before (correlation_class.cpp:413-419, :870); lk_stale_iterations_kernel fills that in
+      r.iterations = (ordered_all && k.n_evals == 1u && k.error != LK_ERROR_NONE && k.lg_chi == FLT_MAX && k.reached == 0)
+                         ? kStaleIterations
+                         : k.reached;
       r.errorCode = team.timed_out ? (int)LK_ERROR_DEVICE : k.error;
       r.undCenterX = k.c0x;
       r.undCenterY = k.c0y;
@@ -1371,7 +1531,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
         a.stats[(size_t)k.s * 4 + 2] = k.n_point_iters;
         a.stats[(size_t)k.s * 4 + 3] = k.n_ill;
       }
-      if (starved) {
+      if (starved && a.handoff) {
         LkHandoff h{};
         h.level = a.py_start - 1; // finished
         a.handoff[k.s] = h;
@@ -1534,7 +1694,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
       // that is otherwise spent waiting for the slowest sectors.
       const unsigned long long act = __ballot(active);
       const bool idle_ok = (a.align && a.persistent) || __ballot(phase == PH_EXIT) == ~act;
-      if (a.solo && width < 64 && idle_ok && !finisher) {
+      if (a.solo && width < 64 && idle_ok && !finisher && !ordered_all) {
         // home rows of the sectors in progress (a widened group shows up in all its rows)
         const unsigned rows = ((act & 0xffffull) ? 1u : 0u) | ((act & 0xffff0000ull) ? 2u : 0u) |
                               ((act & 0xffff00000000ull) ? 4u : 0u) | ((act & 0xffff000000000000ull) ? 8u : 0u);
@@ -1589,8 +1749,14 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
     LevelCtx ce = c;
     if (!active)
       ce.n = 0;
-    const bool err = evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds, &team, wide, finisher,
-                                                             GROUP == 16 ? width : 0);
+    bool err;
+    if constexpr (ORD) {
+      err = ordered_all ? evaluate_ordered<MODEL, INTERP, GROUP>(ce, p, S, ord_lds, a.reference_order)
+                        : evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds, &team, wide, finisher,
+                                                                  GROUP == 16 ? width : 0);
+    } else {
+      err = evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds, &team, wide, finisher, GROUP == 16 ? width : 0);
+    }
     if (active) {
       Cold k = cold.load(cold_slot);
       float evaluated[6]; // the parameters this evaluation ran at (rescaled to level 0 only if the sector ends here)
@@ -1617,8 +1783,9 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
 #pragma unroll
         for (int i = 0; i < P; ++i)
           tent[i] = p[i];
-        // (16-lane SAFE kernel: every lane of a row holds the same system - the QR runs spread over the row)
-        const bool wc = damped_step<P, SAFE || STARVED>(S, lam_use, c.scaling, p, starved, nullptr, SAFE && GROUP == 16); // p += dp
+        // (SAFE kernels up to one wavefront per sector: every lane of a 16-lane row holds the same system - the QR
+        // runs spread over the row)
+        const bool wc = damped_step<P, SAFE || STARVED>(S, lam_use, c.scaling, p, starved, nullptr, SAFE && GROUP >= 16 && GROUP <= kWave); // p += dp
         if (!wc && !starved)
           ++k.n_ill;
         bool ill_parked = false;
@@ -1690,7 +1857,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
         if (k.level < a.py_start) {
           translate<P>(p, k.level_old, 0);
           finished = true;
-        } else if (starved && level_count(k.level, k.s) > 2 * P) {
+        } else if (starved && !ordered_all && level_count(k.level, k.s) > 2 * P) {
           handed = true;
         } else {
           enter_level(k);
@@ -1716,6 +1883,10 @@ __global__ void __launch_bounds__(256) lk_eval_kernel(LkEvalArgs a) {
   constexpr int P = n_params(MODEL);
   using SumsT = Sums<P>;
   __shared__ float lds[4 * (SumsT::N + 1)];
+  constexpr int OG = GROUP == 16 ? 16 : kWave; // lane group of the reference-order evaluation
+  __shared__ __attribute__((aligned(16))) float ord_lds[ord_floats<SumsT::N, OG>()];
+  if (a.ref_threads > 0 && (int)threadIdx.x >= kWave)
+    return; // reference order: one wavefront (its first row or all of it) owns the sector
   const LkLevelView lv = a.lv[a.level];
   const uint32_t off = lv.off[a.sector];
   const float2 c0 = a.center[a.sector];
@@ -1742,7 +1913,14 @@ __global__ void __launch_bounds__(256) lk_eval_kernel(LkEvalArgs a) {
   for (int i = 0; i < 6; ++i)
     p[i] = a.p[i];
   SumsT S;
-  bool err = evaluate<MODEL, INTERP, GROUP, 256>(c, p, S, lds);
+  bool err;
+  if (a.ref_threads > 0) {
+    if (OG == 16 && (int)threadIdx.x >= 16)
+      c.n = 0;
+    err = evaluate_ordered<MODEL, INTERP, OG>(c, p, S, ord_lds, a.ref_threads);
+  } else {
+    err = evaluate<MODEL, INTERP, GROUP, 256>(c, p, S, lds);
+  }
   if (threadIdx.x == 0) {
     for (int i = 0; i < 44; ++i)
       a.out[i] = 0.f;
@@ -2237,7 +2415,41 @@ __global__ void __launch_bounds__(kWave) lk_mean_center_kernel(const float2 *xy,
   }
 }
 
+// Reference-order mode.  CorrelationClass::reached_iterations is a member that only an LM trip
+// writes (correlation_class.cpp:452); a sector whose very first evaluation fails returns before any
+// trip (:413-419), and get_iterations() (:870) reports the value the sector BEFORE it left behind -
+// the manager solves sectors one after the other in index order (manager_class.cpp:304-307).  The
+// solve kernel marks such records; here every marked record takes the count of the nearest earlier
+// unmarked sector (or `carry_in`: what the last sector of the previous solve left; 0 at first - the
+// reference's own first value is indeterminate).  Marked records are rare and their runs short.
+__global__ void lk_stale_iterations_kernel(lk_result *r, int n, const int *carry_in, int *carry_out) {
+  const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (s >= n)
+    return;
+  int *it = &r[s].iterations;
+  int v = __hip_atomic_load(it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (v == kStaleIterations) {
+    int t = s - 1;
+    // (a marked neighbour may already hold its resolved value: the same value the walk would reach)
+    while (t >= 0 && (v = __hip_atomic_load(&r[t].iterations, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kStaleIterations)
+      --t;
+    if (t < 0)
+      v = *carry_in;
+    __hip_atomic_store(it, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (s == n - 1)
+    *carry_out = v;
+}
+
 } // namespace
+
+hipError_t lk_launch_stale_iterations(lk_result *r, int n, const int *carry_in, int *carry_out, hipStream_t st) {
+  if (n <= 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(lk_stale_iterations_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, r, n, carry_in,
+                     carry_out);
+  return hipGetLastError();
+}
 
 // ------------------------------------------------------------------------------------
 // launch wrappers (called from lk_engine.cpp)

@@ -76,6 +76,10 @@ class HipCorrelationEngine:
     def set_batch_invariant(self, enabled):
         self._chk(self.lib.lk_set_batch_invariant(self._h, int(bool(enabled))))
 
+    def set_reference_order(self, threads=1):
+        """Bit-identical records to the CPU engine with number_of_threads = threads (0: off)."""
+        self._chk(self.lib.lk_set_reference_order(self._h, int(threads)))
+
     def set_pairs_in_flight(self, n):
         """lk_set_pairs_in_flight: how many engines solve side by side on this GPU (before commit)."""
         self._chk(self.lib.lk_set_pairs_in_flight(self._h, int(n)))

@@ -119,6 +119,21 @@ int lk_set_timing(lk_engine *e, int enabled);
  * the batch's): a sector then gets the same bits in any batch, shard or single-sector call
  * (about 20 % slower on small grids).  Call it before lk_commit_sectors. */
 int lk_set_batch_invariant(lk_engine *e, int enabled);
+/* Reference-order mode.  threads = T > 0: every evaluation of every sector at every pyramid level
+ * adds its A, b and chi in the CPU engine's own order for number_of_threads = T - rounded
+ * product, then rounded add, sample by sample (x outer / y inner for rectangles,
+ * interpolation_class.cpp:722-749), in T contiguous chunks joined in thread order
+ * (correlation_class.cpp:169-186, :253-275) - and every damped system goes through the restated
+ * ColPivHouseholderQR (correlation_class.cpp:742-747).  The 48-byte records are then bit-identical
+ * to CorrelationClass::Newton_Raphson's (as restated by the repository's CPU checker) for that
+ * thread count (T = 1: one running sum; the reference's compile-time default is 20, defines.hpp).  The records
+ * are also independent of batch composition.  The sample work stays parallel (a 16-lane row or a
+ * wavefront per sector forms the per-sample products and transposes them through LDS; only the
+ * additions of each sum run as a chain), so the mode costs about 1.5-2x the default's time, not
+ * the serial loop's.  threads = 0 (default): lane-parallel sums and the root-free Cholesky solve,
+ * which differ from the reference by summation order and solver rounding only.
+ * May be called at any time; the lane groups are re-chosen before the next solve. */
+int lk_set_reference_order(lk_engine *e, int threads);
 /* Independent image pairs can be solved side by side: one engine per pair in flight, each on
  * its own stream (lk_set_stream).  A solve ends in a tail of slow sectors that leaves most of
  * the GPU idle; the next pair's solve fills it (C2: 0.26 ms per pair one at a time, 0.15 ms

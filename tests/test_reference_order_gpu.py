@@ -1,0 +1,254 @@
+"""Reference-order mode (lk_set_reference_order): BITWISE parity of the 48-byte records.
+
+In this mode every evaluation adds A, b and chi in the CPU engine's own order (rounded product,
+rounded add, sample by sample; `number_of_threads` contiguous chunks joined in thread order:
+interpolation_class.cpp:722-749, correlation_class.cpp:169-186, :253-275) and every damped system
+goes through the restated ColPivHouseholderQR (correlation_class.cpp:742-747), at EVERY pyramid
+level.  Per-sample quantities were already bit-exact (test_parity_gpu.py), so nothing is left that
+may differ: the engine's records must equal the oracle's byte for byte - parameters, chi,
+iterations, error codes, NaNs and all.  The default (fast) mode then deviates from these records by
+summation order and solver rounding only.
+"""
+import numpy as np
+import pytest
+
+import correlation_amd as ca
+from correlation_amd import workload as wl
+
+pytestmark = pytest.mark.gpu
+
+
+def engine_and_oracle(oracle, pair, model=ca.FM_UVUXUYVXVY, interp=ca.IM_BICUBIC, threads=1, **kw):
+    und, dfm = pair
+    e = ca.HipCorrelationEngine(interpolation=interp, fitting_model=model, **kw)
+    e.set_reference_order(threads)
+    e.set_undeformed_image(und)
+    e.set_deformed_image(dfm)
+    o = oracle.Oracle(interp=interp, model=model, n_threads=threads, **kw)
+    o.set_image(0, und)
+    o.set_image(1, dfm)
+    return e, o
+
+
+def canonical(rec):
+    """Records with every NaN replaced by ONE quiet-NaN pattern.  IEEE 754 leaves the sign and payload
+    of a generated NaN to the platform: x86 SSE produces 0xFFC00000 ("real indefinite"), gfx950
+    0x7FC00000.  WHERE the NaNs are must agree; which NaN it is cannot."""
+    a = np.array(rec, copy=True)
+    for f in ("p", "chi", "und_cx", "und_cy"):
+        v = a[f]
+        v[np.isnan(v)] = np.float32(np.nan)
+    return a
+
+
+def assert_same_bytes(got, want, label):
+    got, want = canonical(np.atleast_1d(got)), canonical(np.atleast_1d(want))
+    if got.tobytes() == want.tobytes():
+        return
+    diff = [i for i in range(len(got)) if got[i].tobytes() != want[i].tobytes()]
+    i = diff[0]
+    raise AssertionError(f"{label}: {len(diff)} of {len(got)} records differ; first: sector {i}\n got  {got[i]}\n want {want[i]}")
+
+
+def grid_lists(oracle, w, first, count):
+    xd, yd, cen = oracle.rect_sector_geometry(w.x_begin, w.x_begin, w.x_end, w.x_end, w.hs, w.vs)
+    cen = cen[first:first + count]
+    lists = [oracle.rect_points(cx - xd, cy - yd, cx + xd, cy + yd) for cx, cy in cen]
+    return lists, cen.astype(np.float32)
+
+
+@pytest.mark.parametrize("model", [ca.FM_UV, ca.FM_UVUXUYVXVY])
+@pytest.mark.parametrize("threads", [1, 20])
+def test_config1_records_are_bit_identical(oracle, speckle512, model, threads):
+    """BASELINE config 1: one 201x201 sector (40 401 samples, a wavefront in reference-order mode),
+    rigid and affine, for one thread and for the reference's default of 20."""
+    e, o = engine_and_oracle(oracle, speckle512, model, threads=threads)
+    e.resetPolygon_rect(0, 156, 156, 356, 356)
+    e.commit_sectors()
+    P = ca.N_PARAMS[model]
+    got, guess = e.correlate(0, np.zeros(P, np.float32))
+    want = o.newton_raphson(np.zeros(P), oracle.rect_points(156, 156, 356, 356), center=(256.0, 256.0))
+    assert_same_bytes(np.array([got]), np.array([want]), f"config 1 model {model} T={threads}")
+    assert got["error_code"] == 0 and abs(got["p"][0] - 1.3) < 0.02
+    assert np.array_equal(guess[:P], got["p"][:P])
+    assert_same_bytes(e.correlate_all(np.zeros(6, np.float32)), np.array([want]), "batch entry point")
+    e.close()
+
+
+@pytest.mark.parametrize("model", [ca.FM_U, ca.FM_UV, ca.FM_UVQ, ca.FM_UVUXUYVXVY])
+@pytest.mark.parametrize("interp", [ca.IM_NEAREST, ca.IM_BILINEAR, ca.IM_BICUBIC])
+def test_evaluation_sums_are_bit_identical(oracle, speckle512, model, interp):
+    """One evaluation: A, b, chi bit for bit, at three levels, 16-lane row and wavefront flavour."""
+    for x1, y1 in ((255, 216), (270, 232)):   # 16 x 17 = 272 samples (row of 16 lanes), 31 x 33 = 1023 (wavefront)
+        e, o = engine_and_oracle(oracle, speckle512, model, interp)
+        xy = oracle.rect_points(240, 200, x1, y1)
+        cx, cy = 250.0, 210.0
+        e.set_sector_points(0, xy, center=(cx, cy))
+        e.commit_sectors()
+        P = ca.N_PARAMS[model]
+        p = np.array([1.1, -0.6, 0.003, -0.002, 0.001, 0.002], np.float32)[:P]
+        for lvl in (0, 1, 2):
+            lxy = xy if lvl == 0 else oracle.decimate(xy, lvl)
+            pl = p.copy()
+            pl[:min(P, 2)] /= (1 << lvl)
+            A, b, chi, err = e.evaluate(0, lvl, pl)
+            Ao, bo, chio, erro = oracle.evaluate(interp, model, o.get_level(0, lvl), o.get_level(1, lvl), lxy,
+                                                 np.float32(cx) * np.float32(1.0 / (1 << lvl)),
+                                                 np.float32(cy) * np.float32(1.0 / (1 << lvl)), pl)
+            assert err == erro == 0
+            iu = np.triu_indices(P)
+            assert np.array_equal(A[:P, :P][iu], Ao[:P, :P][iu]), (lvl, len(lxy))
+            assert np.array_equal(b[:P], bo[:P]) and np.float32(chi) == np.float32(chio)
+        e.close()
+
+
+@pytest.mark.parametrize("threads", [1, 8, 20])
+def test_config2_sectors_are_bit_identical(oracle, threads):
+    """1000 seeded sectors of BASELINE config 2 (2048^2 pair, 19x19 samples, affine, 3 levels)."""
+    w = wl.C2
+    pair = ca.speckle.speckle_pair(w.size, w.size, p=w.truth, seed=7)
+    e, o = engine_and_oracle(oracle, pair, threads=threads, py_stop=w.py_stop)
+    first, count = 4200, 1000
+    e.set_rect_grid(w.x_begin, w.x_begin, w.x_end, w.x_end, w.hs, w.vs, first, count)
+    e.commit_sectors()
+    got = e.correlate_all(np.zeros(6, np.float32))
+    lists, cen = grid_lists(oracle, w, first, count)
+    want = o.correlate_sectors(lists, centers=cen)
+    assert_same_bytes(got, want, f"C2 T={threads}")
+    assert (got["error_code"] == 0).all() and np.abs(got["p"][:, 0] - 1.3).max() < 0.5
+    # single-sector entry point, and a different batch around the same sectors: same bytes
+    one, _ = e.correlate(17, np.zeros(6, np.float32))
+    assert_same_bytes(one, want[17], "single-sector entry point")
+    e.set_rect_grid(w.x_begin, w.x_begin, w.x_end, w.x_end, w.hs, w.vs, first + 300, 333)
+    e.commit_sectors()
+    assert_same_bytes(e.correlate_all(np.zeros(6, np.float32)), want[300:633], "C2 sub-batch")
+    e.close()
+
+
+def test_switching_modes_on_a_committed_engine(oracle, speckle512):
+    """lk_set_reference_order may come after lk_commit_sectors and may be switched off again."""
+    e, o = engine_and_oracle(oracle, speckle512, threads=0)
+    e.set_rect_grid(24.0, 24.0, 487.0, 487.0, 10, 10)
+    e.commit_sectors()
+    fast = e.correlate_all(np.zeros(6, np.float32))
+    e.set_reference_order(1)
+    xd, yd, cen = oracle.rect_sector_geometry(24.0, 24.0, 487.0, 487.0, 10, 10)
+    lists = [oracle.rect_points(cx - xd, cy - yd, cx + xd, cy + yd) for cx, cy in cen]
+    o1 = oracle.Oracle()
+    o1.set_image(0, speckle512[0])
+    o1.set_image(1, speckle512[1])
+    want = o1.correlate_sectors(lists, centers=cen.astype(np.float32))
+    assert_same_bytes(e.correlate_all(np.zeros(6, np.float32)), want, "after switching on")
+    e.set_reference_order(0)
+    assert e.correlate_all(np.zeros(6, np.float32)).tobytes() == fast.tobytes()
+    # the fast mode deviates from the reference-order records by summation order only
+    assert np.abs(fast["p"] - want["p"])[:, :2].max() < 5e-3
+    assert np.array_equal(fast["error_code"], want["error_code"])
+    e.close()
+
+
+def test_annular_and_blob_sectors_are_bit_identical(oracle):
+    """Explicit sample lists (annular wedges, a full ring, a star-shaped blob; 2.6 k - 150 k samples),
+    centre = the float mean of the samples."""
+    und, dfm = ca.speckle.speckle_pair(768, 768, p=(0.9, 0.4, 0.001, 0.0005, -0.0005, 0.0015), seed=21)
+    e, o = engine_and_oracle(oracle, (und, dfm))
+    lists = []
+    rs, as_ = 2, 4
+    ri, ro, cx, cy = 120.0, 330.0, 384.0, 384.0
+    dr, da = (ro - ri) / rs, np.float32(2 * np.pi) / np.float32(as_)
+    s = 0
+    for i in range(rs):
+        for j in range(as_):
+            r, a = np.float32(ri + i * dr), np.float32(j) * da
+            e.resetPolygon_annular(s, r, dr, a, da, cx, cy, as_)
+            lists.append(oracle.annular_points(r, dr, a, da, cx, cy, as_))
+            s += 1
+    e.resetPolygon_annular(s, 40.0, 60.0, 0.0, 2 * np.pi, 384.0, 384.0, 1)
+    lists.append(oracle.annular_points(40.0, 60.0, 0.0, np.float32(2 * np.pi), 384.0, 384.0, 1))
+    s += 1
+    t = 2 * np.pi * np.arange(24) / 24
+    rad = np.where(np.arange(24) % 2 == 0, 300.0, 190.0)
+    contour = np.stack([384 + rad * np.cos(t), 384 + rad * np.sin(t)], 1).astype(np.float32)
+    e.resetPolygon_blob(s, contour)
+    lists.append(oracle.blob_points(contour))
+    e.commit_sectors()
+    got = e.correlate_all(np.zeros(6, np.float32))
+    want = o.correlate_sectors(lists)
+    assert_same_bytes(got, want, "annular + blob")
+    assert (got["error_code"] == 0).all()
+    e.close()
+
+
+def test_config4_subset_is_bit_identical_including_nans(oracle):
+    """3000 of BASELINE config 4's 7x7-sample sectors: levels 1 and 2 hold 9-16 and 1-4 samples for six
+    parameters, the rank-revealing QR decides the steps, a few sectors end in max_iters or NaN
+    parameters with error code 0 - whatever the oracle returns there, the engine returns the same bytes."""
+    w = wl.C4
+    pair = ca.speckle.speckle_pair(w.size, w.size, p=w.truth, seed=7)
+    e, o = engine_and_oracle(oracle, pair, py_stop=w.py_stop)
+    got_all, want_all = [], []
+    for first in (20000, 31000, 38000):   # (the full grid's NaN records sit at sectors 32222 and 38780)
+        count = 1000 if first != 31000 else 1500
+        e.set_rect_grid(w.x_begin, w.x_begin, w.x_end, w.x_end, w.hs, w.vs, first, count)
+        e.commit_sectors()
+        got_all.append(e.correlate_all(np.zeros(6, np.float32)))
+        lists, cen = grid_lists(oracle, w, first, count)
+        want_all.append(o.correlate_sectors(lists, centers=cen))
+    got, want = np.concatenate(got_all), np.concatenate(want_all)
+    assert_same_bytes(got, want, "C4")
+    nan_got, nan_want = np.isnan(got["p"]).any(1), np.isnan(want["p"]).any(1)
+    assert np.array_equal(nan_got, nan_want)
+    print(f"C4 subset: {len(got)} sectors, error codes {np.bincount(want['error_code'], minlength=4).tolist()}, "
+          f"NaN records {int(nan_want.sum())}")
+    e.close()
+
+
+def test_config5_subset_is_bit_identical(oracle):
+    """3000 sectors of BASELINE config 5's geometry (17x17 samples, 4 levels, 2x2..3x3 samples at level 3)
+    on a 2048^2 stand-in of its 8192^2 pair (same sector grid pitch, same starved level)."""
+    und, dfm = ca.speckle.speckle_pair(2048, 2048, p=(1.3, -0.7, 0.0005, 0.0, 0.0, -0.00025), seed=13)
+    e, o = engine_and_oracle(oracle, (und, dfm), py_stop=3)
+    # C5's pitch: (8159 - 32) / 447 = 18.18 px per sector -> 111 sectors on [32, 2050) does not fit; use 110
+    x0, x1, hs = 32.0, 2031.0, 110
+    xd, yd, cen = oracle.rect_sector_geometry(x0, x0, x1, x1, hs, hs)
+    assert xd == 8 and yd == 8
+    first, count = 4000, 3000
+    e.set_rect_grid(x0, x0, x1, x1, hs, hs, first, count)
+    e.commit_sectors()
+    assert e.sector_info(0)[0] == 289 and e.sector_level_count(0, 3) <= 9
+    got = e.correlate_all(np.zeros(6, np.float32))
+    cen = cen[first:first + count]
+    lists = [oracle.rect_points(cx - xd, cy - yd, cx + xd, cy + yd) for cx, cy in cen]
+    want = o.correlate_sectors(lists, centers=cen.astype(np.float32))
+    assert_same_bytes(got, want, "C5 geometry")
+    e.close()
+
+
+def test_error_paths_and_ragged_sectors_are_bit_identical(oracle, speckle512):
+    """Out-of-image at evaluation #0 and inside the loop, max_iters = 0, sectors of 1-5 samples,
+    every model."""
+    for model in (ca.FM_U, ca.FM_UV, ca.FM_UVQ, ca.FM_UVUXUYVXVY):
+        e, o = engine_and_oracle(oracle, speckle512, model)
+        xs = [oracle.rect_points(0, 0, 20, 20), oracle.rect_points(200, 200, 240, 240),
+              oracle.rect_points(490, 470, 510, 500), oracle.rect_points(300, 300, 300, 300),
+              oracle.rect_points(301, 300, 302, 301), oracle.rect_points(100, 100, 104, 100),
+              oracle.rect_points(3, 3, 30, 30)]
+        cs = [(10.0, 10.0), (220.0, 220.0), (500.0, 485.0), (300.0, 300.0), (301.5, 300.5), (102.0, 100.0), (16.0, 16.0)]
+        for i, (xy, c) in enumerate(zip(xs, cs)):
+            e.set_sector_points(i, xy, center=c)
+        e.commit_sectors()
+        g = np.tile(np.array([0.5, 0.25, 0, 0, 0, 0], np.float32), (len(xs), 1))
+        g[6, :2] = (-2.5, -2.5)     # drifts out of the image inside the loop
+        got = e.correlate_all(g)
+        want = o.correlate_sectors(xs, centers=np.array(cs, np.float32), guesses=g)
+        assert_same_bytes(got, want, f"error paths, model {model}")
+        assert got["error_code"][0] == 2 and got["error_code"][1] == 0
+        e.close()
+    e0, o0 = engine_and_oracle(oracle, speckle512, ca.FM_UV, max_iters=0)
+    xy = oracle.rect_points(200, 200, 240, 240)
+    e0.set_sector_points(0, xy, center=(220.0, 220.0))
+    e0.commit_sectors()
+    got0 = e0.correlate_all(np.zeros(6, np.float32))
+    assert_same_bytes(got0[0], o0.newton_raphson([0, 0], xy, center=(220.0, 220.0)), "max_iters = 0")
+    assert got0["error_code"][0] == 3
+    e0.close()
