@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblk_engine.so")
+LIB_PATH = os.environ.get("LK_ENGINE_LIB") or os.path.join(_HERE, "liblk_engine.so")  # (LK_ENGINE_LIB: tuning builds)
 
 LK_MAX_LEVELS = 8
 

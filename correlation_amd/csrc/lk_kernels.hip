@@ -90,12 +90,19 @@ __device__ __forceinline__ float ub3(uint32_t v) { return (float)(v >> 24); }
 // partial sum is a multiple of 1/4 below 2^24/4 in magnitude, hence exactly representable
 // in float32: the factored form, in any order and with FMAs, yields the reference's
 // coefficients bit for bit (tests/test_parity_gpu.py::test_bicubic_coefficients_exact).
+// c = Cm * p with Cm = [2 -3 3 -1; -4 9.5 -8 2.5; 2.5 -7 6.5 -2; -0.5 1.5 -1.5 0.5] in 11 operations
+// instead of 16, through the identities the cubic itself provides (value and slope at dx = 1):
+//   e = (p3 - p0) + 3 (p1 - p2),  c3 = e / 2,  c0 = p0 - e,
+//   c1 + c2 = p1 - c0 - c3,       c1 + 2 c2 + 3 c3 = (p2 - p0) / 2.
+// Exact like the matrix form: every intermediate is a multiple of 1/4 below 2^22 in magnitude.
 __device__ __forceinline__ void cubic_1d(float p0, float p1, float p2, float p3, float &c0,
                                          float &c1, float &c2, float &c3) {
-  c0 = __builtin_fmaf(2.0f, p0, __builtin_fmaf(-3.0f, p1, __builtin_fmaf(3.0f, p2, -p3)));
-  c1 = __builtin_fmaf(-4.0f, p0, __builtin_fmaf(9.5f, p1, __builtin_fmaf(-8.0f, p2, 2.5f * p3)));
-  c2 = __builtin_fmaf(2.5f, p0, __builtin_fmaf(-7.0f, p1, __builtin_fmaf(6.5f, p2, -2.0f * p3)));
-  c3 = __builtin_fmaf(-0.5f, p0, __builtin_fmaf(1.5f, p1, __builtin_fmaf(-1.5f, p2, 0.5f * p3)));
+  const float e = __builtin_fmaf(3.0f, p1 - p2, p3 - p0);
+  c3 = 0.5f * e;
+  c0 = p0 - e;
+  const float u = (p1 - c0) - c3;
+  c2 = __builtin_fmaf(-3.0f, c3, __builtin_fmaf(0.5f, p2 - p0, -u));
+  c1 = u - c2;
 }
 
 // the 4x4 window as four (unaligned) dwords, rows iy-1..iy+2, columns ix-1..ix+2
@@ -113,10 +120,9 @@ __device__ __forceinline__ Window4 load_window(gptr<uint8_t> def, int cols, int 
 }
 
 // Value and gradient of the bicubic at (ix + dx - 1, iy + dy - 1), dx,dy in [1,2).
-// The four coefficients of monomial row jk are produced (exactly, see above) right before
-// they are consumed, so only the 16 x-transformed values stay live, and then W, dW/dx,
-// dW/dy are accumulated in the reference's order (:94-126): three running sums, jk outer /
-// ik inner, each term built left to right.
+// The 16 coefficients are produced exactly (see above) by 4 + 4 one-dimensional transforms, and
+// then W, dW/dx, dW/dy are accumulated in the reference's order (:94-126): three running sums,
+// jk outer / ik inner, each term built left to right.
 __device__ __forceinline__ void bicubic_sample(gptr<uint8_t> def, int cols, int ix, int iy, float dx,
                                                float dy, float &W, float &Wx, float &Wy) {
   gptr<uint8_t> base = def + (size_t)(iy - 1) * (size_t)cols + (size_t)(ix - 1);
@@ -130,10 +136,11 @@ __device__ __forceinline__ void bicubic_sample(gptr<uint8_t> def, int cols, int 
   cubic_1d(ub0(r1), ub1(r1), ub2(r1), ub3(r1), t1[0], t1[1], t1[2], t1[3]);
   cubic_1d(ub0(r2), ub1(r2), ub2(r2), ub3(r2), t2[0], t2[1], t2[2], t2[3]);
   cubic_1d(ub0(r3), ub1(r3), ub2(r3), ub3(r3), t3[0], t3[1], t3[2], t3[3]);
-  constexpr float Cm[4][4] = {{2.0f, -3.0f, 3.0f, -1.0f},
-                              {-4.0f, 9.5f, -8.0f, 2.5f},
-                              {2.5f, -7.0f, 6.5f, -2.0f},
-                              {-0.5f, 1.5f, -1.5f, 0.5f}};
+  // y-direction transform, column by column: a[jk][ik] (exact in any order)
+  float a0[4], a1[4], a2[4], a3[4];
+#pragma unroll
+  for (int ik = 0; ik < 4; ++ik)
+    cubic_1d(t0[ik], t1[ik], t2[ik], t3[ik], a0[ik], a1[ik], a2[ik], a3[ik]);
   const float px[4] = {1.f, dx, dx * dx, dx * dx * dx};
   const float py[4] = {1.f, dy, dy * dy, dy * dy * dy};
   W = 0.f;
@@ -143,10 +150,7 @@ __device__ __forceinline__ void bicubic_sample(gptr<uint8_t> def, int cols, int 
   for (int jk = 0; jk < 4; ++jk) {
 #pragma unroll
     for (int ik = 0; ik < 4; ++ik) {
-      // y-direction transform, coefficient a[jk][ik] (exact in any order)
-      const float c = __builtin_fmaf(
-          Cm[jk][0], t0[ik],
-          __builtin_fmaf(Cm[jk][1], t1[ik], __builtin_fmaf(Cm[jk][2], t2[ik], Cm[jk][3] * t3[ik])));
+      const float c = jk == 0 ? a0[ik] : jk == 1 ? a1[ik] : jk == 2 ? a2[ik] : a3[ik];
       W += c * py[jk] * px[ik];
       if (ik > 0)
         Wx += (float)ik * c * py[jk] * px[ik - 1];
@@ -1361,6 +1365,11 @@ template <bool IN_LDS> struct ColdStore {
 #ifndef LK_MIN_WAVES
 #define LK_MIN_WAVES 1
 #endif
+#ifdef LK_TRACE
+// tuning builds only (scripts/tune_build.sh NAME -DLK_TRACE): per-wavefront timeline of a solve launch,
+// 8 words per workgroup: start, end, cycles inside evaluate<>, steps, HW_ID, XCC_ID, first sector, -
+__device__ unsigned long long g_lk_trace[8 * 16384];
+#endif
 template <int MODEL, int INTERP, int GROUP, int THREADS, bool SAFE>
 __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) lk_solve_kernel(LkSolveArgs a) {
   constexpr int P = n_params(MODEL);
@@ -1540,6 +1549,11 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
     phase = PH_FETCH;
   };
 
+#ifdef LK_TRACE
+  const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz, one clock for the whole device
+  const unsigned long long tr_c0 = __builtin_amdgcn_s_memtime();
+  unsigned long long tr_eval = 0, tr_steps = 0;
+#endif
   for (;;) {
     bool may_fetch = true;
     if constexpr (GROUP > 1 && GROUP < kWave) {
@@ -1749,6 +1763,9 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
     LevelCtx ce = c;
     if (!active)
       ce.n = 0;
+#ifdef LK_TRACE
+    const unsigned long long tr_e0 = __builtin_amdgcn_s_memtime();
+#endif
     bool err;
     if constexpr (ORD) {
       err = ordered_all ? evaluate_ordered<MODEL, INTERP, GROUP>(ce, p, S, ord_lds, a.reference_order)
@@ -1757,6 +1774,10 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
     } else {
       err = evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds, &team, wide, finisher, GROUP == 16 ? width : 0);
     }
+#ifdef LK_TRACE
+    tr_eval += __builtin_amdgcn_s_memtime() - tr_e0;
+    ++tr_steps;
+#endif
     if (active) {
       Cold k = cold.load(cold_slot);
       float evaluated[6]; // the parameters this evaluation ran at (rescaled to level 0 only if the sector ends here)
@@ -1875,6 +1896,24 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
         cold.store(cold_slot, k);
     }
   }
+#ifdef LK_TRACE
+  if constexpr (GROUP > 1 && !SAFE) {
+    if (((int)threadIdx.x & 63) == 0 && blockIdx.x < 16384u) {
+      unsigned long long *w = g_lk_trace + 8 * ((size_t)blockIdx.x);
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      w[0] = tr_t0;
+      w[1] = __builtin_amdgcn_s_memrealtime();
+      w[2] = tr_eval;
+      w[3] = tr_steps;
+      w[4] = hw;
+      w[5] = xcc;
+      w[6] = __builtin_amdgcn_s_memtime() - tr_c0; // shader cycles of the whole wavefront
+      w[7] = gridDim.x;
+    }
+  }
+#endif
 }
 
 // stand-alone evaluation of one sector/level (known-answer tests): same evaluate<>()
@@ -2443,6 +2482,12 @@ __global__ void lk_stale_iterations_kernel(lk_result *r, int n, const int *carry
 
 } // namespace
 
+#ifdef LK_TRACE
+extern "C" int lk_debug_trace(unsigned long long *out, int n_words) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lk_trace), (size_t)n_words * 8);
+}
+#endif
+
 hipError_t lk_launch_stale_iterations(lk_result *r, int n, const int *carry_in, int *carry_out, hipStream_t st) {
   if (n <= 0)
     return hipSuccess;
@@ -2552,12 +2597,16 @@ static hipError_t launch_solve_mi(const LkSolveArgs &a, int group, hipStream_t s
   }
 }
 
+// LK_TUNE_ONLY_AFFINE_BICUBIC (kernel tuning builds, scripts/tune_build.sh): instantiate the solve
+// kernel for the affine model with the reference bicubic only - a 15 s build instead of 90 s
 template <int MODEL>
 static hipError_t launch_solve_m(const LkSolveArgs &a, int interp, int group, hipStream_t st) {
   switch (interp) {
+#ifndef LK_TUNE_ONLY_AFFINE_BICUBIC
   case LK_IM_NEAREST: return launch_solve_mi<MODEL, LK_IM_NEAREST>(a, group, st);
   case LK_IM_BILINEAR: return launch_solve_mi<MODEL, LK_IM_BILINEAR>(a, group, st);
   case LK_IM_BICUBIC_SEPARABLE: return launch_solve_mi<MODEL, LK_IM_BICUBIC_SEPARABLE>(a, group, st);
+#endif
   default: return launch_solve_mi<MODEL, LK_IM_BICUBIC>(a, group, st);
   }
 }
@@ -2566,9 +2615,11 @@ hipError_t lk_launch_solve(const LkSolveArgs &a, int model, int interp, int grou
   if (a.n_sectors <= 0)
     return hipSuccess;
   switch (model) {
+#ifndef LK_TUNE_ONLY_AFFINE_BICUBIC
   case LK_FM_U: return launch_solve_m<LK_FM_U>(a, interp, group, st);
   case LK_FM_UV: return launch_solve_m<LK_FM_UV>(a, interp, group, st);
   case LK_FM_UVQ: return launch_solve_m<LK_FM_UVQ>(a, interp, group, st);
+#endif
   default: return launch_solve_m<LK_FM_UVUXUYVXVY>(a, interp, group, st);
   }
 }

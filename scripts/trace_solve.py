@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Per-wavefront timeline of one C2 solve launch (tuning build with -DLK_TRACE, see tune_build.sh):
+LK_ENGINE_LIB=build/tune/liblk_trace.so python scripts/trace_solve.py [out.npz]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import correlation_amd as ca  # noqa: E402
+from correlation_amd.workload import C2 as wl  # noqa: E402
+
+und, dfm = ca.speckle.speckle_pair(wl.size, wl.size, p=wl.truth, seed=7)
+e = ca.HipCorrelationEngine(fitting_model=wl.model, py_stop=wl.py_stop)
+e.set_undeformed_image(und)
+e.set_deformed_image(dfm)
+e.set_rect_grid(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, wl.hs, wl.vs)
+e.commit_sectors()
+g = np.zeros(6, np.float32)
+for _ in range(3):
+    r = e.correlate_all(g)
+st = e.stats()
+lib = C.CDLL(ca.LIB_PATH)
+buf = np.zeros(8 * 16384, np.uint64)
+assert lib.lk_debug_trace(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
+t = buf.reshape(-1, 8)
+n = int(t[0, 7])
+t = t[:n]
+np.savez_compressed(sys.argv[1] if len(sys.argv) > 1 else "/tmp/trace.npz", trace=t, solve_ms=st["solve_ms"])
+print("saved; analyse with scripts/trace_report.py")
