@@ -42,7 +42,9 @@ def build(force=False, verbose=False):
         # to the sample loop (measured: 6 % slower with it)
         "-fno-slp-vectorize",
         "-Wall", "-Wextra", "-o", LIB,
-    ] + os.environ.get("LK_EXTRA_HIPCC_FLAGS", "").split() + SOURCES  # (tuning experiments)
+    ] + os.environ.get("LK_EXTRA_HIPCC_FLAGS", "").split() + SOURCES + [  # (tuning experiments)
+        "-lrocprofiler-sdk-roctx",   # roctx ranges (lk_engine.cpp: struct Range)
+    ]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)

@@ -45,7 +45,8 @@ struct LkSolveArgs {
   int team_w;
   int team_min_samples;  // a sector's team has ceil(n0 / team_min_samples) workgroups (<= team_w)
   float *team_partials;  // [n_sectors][2][team_w][32]: per-workgroup sums, double-buffered by step parity
-  uint32_t *team_arrivals; // [n_sectors]: monotonic arrival counter (zeroed per launch)
+  uint32_t *team_arrivals; // [2][n_sectors]: monotonic arrival counters, then "team is broken" flags (zeroed per launch)
+  int team_fault;          // test hook (LK_TEAM_FAULT = step): rank 1 of every team goes missing at that step
   // Stragglers of the starved-level kernel: after `eval_cap` evaluations a lane parks its sector
   // mid-level (kLkMidWords words of state) and appends it to `finish_list`; the 16-lane
   // finisher (`finisher` = 1) resumes it with reference-order sums spread over 16 lanes.

@@ -15,6 +15,8 @@
 #include "lk_device.hpp"
 #include "lk_roi.hpp"
 
+#include <rocprofiler-sdk-roctx/roctx.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -48,6 +50,17 @@ hipError_t lk_launch_mean_center(const float2 *xy, const uint32_t *off, int n_se
 
 namespace {
 
+// roctx ranges where the reference has NVTX ranges (cuda_class.cu:133,277,310-326,497-511,528,554,
+// cuda_polygon.cu:237,247, cuda_pyramid.cu:219,226): upload + pyramid, sector commit / rebuild,
+// solve, record gather.  `rocprofv3 --marker-trace --kernel-trace` shows them over the kernels;
+// without a profiler attached a push / pop pair is two calls into an empty table.
+struct Range {
+  explicit Range(const char *name) { (void)roctxRangePushA(name); }
+  ~Range() { (void)roctxRangePop(); }
+  Range(const Range &) = delete;
+  Range &operator=(const Range &) = delete;
+};
+
 int n_params_of(int model) {
   switch (model) {
   case LK_FM_U: return 1;
@@ -74,6 +87,7 @@ struct HostSector {
   float cx = 0.f, cy = 0.f;
   bool has_center = false; // the solve centre was given (rectangular path) rather than the samples' mean
   bool set = false;
+  bool fresh = true; // registered (lk_set_sector_*) since the last commit: its sequence state starts from zero
   int n0() const { return is_rect ? (x1 - x0 + 1) * (y1 - y0 + 1) : (int)(xy.size() / 2); }
   std::vector<float> points() const { // level-0 list in the CPU engine's order
     if (!is_rect)
@@ -102,6 +116,22 @@ template <class T> struct DevBuf {
     hipError_t e = hipMalloc((void **)&p, std::max<size_t>(want, 1) * sizeof(T));
     if (e == hipSuccess)
       n = want;
+    return e;
+  }
+  // grow, keeping the first `keep` elements (a commit that adds sectors keeps the state of the others)
+  hipError_t ensure_keep(size_t want, size_t keep) {
+    if (want <= n && p)
+      return hipSuccess;
+    T *q = nullptr;
+    hipError_t e = hipMalloc((void **)&q, std::max<size_t>(want, 1) * sizeof(T));
+    if (e != hipSuccess)
+      return e;
+    if (p && keep)
+      e = hipMemcpy(q, p, std::min(keep, n) * sizeof(T), hipMemcpyDeviceToDevice);
+    if (p)
+      (void)hipFree(p);
+    p = q;
+    n = want;
     return e;
   }
   void release() {
@@ -407,6 +437,7 @@ static int prepare_slot(lk_engine *e, DevImage &im, int rows, int cols, hipStrea
 
 static int set_image_common(lk_engine *e, int slot, const void *src, bool src_on_device, int rows,
                             int cols, int step) {
+  Range range_("lk:upload+pyramid");
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
   if (slot < 0 || slot > 2 || !src || rows < 1 || cols < 1 || step < cols)
@@ -487,6 +518,7 @@ static void swap_images(DevImage &a, DevImage &b) { std::swap(a, b); }
 // for device-resident frames both uploads and both pairs of pyramid levels share ONE launch.
 int lk_set_image_pair_device(lk_engine *e, const void *und_pixels, int und_step, const void *def_pixels,
                              int def_step, int rows, int cols) {
+  Range range_("lk:upload+pyramid pair");
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
   if (!und_pixels || !def_pixels || rows < 1 || cols < 1 || und_step < cols || def_step < cols)
@@ -624,6 +656,7 @@ static HostSector *sector_slot(lk_engine *e, int sector) {
   if ((size_t)sector >= e->hs.size())
     e->hs.resize((size_t)sector + 1);
   e->committed = false;
+  e->hs[(size_t)sector].fresh = true;
   return &e->hs[(size_t)sector];
 }
 
@@ -800,6 +833,7 @@ static int refresh_starved(lk_engine *e) {
 // keep_state: a re-commit after the sample lists moved (Lagrangian descriptions) keeps the
 // sequence state of the sectors (guess history, last results)
 static int commit_impl(lk_engine *e, bool keep_state) {
+  Range range_("lk:commit sectors");
   if (int rc = materialize_host(e)) // (a no-op after any edit: editors fetch the lists first)
     return rc;
   const int S = (int)e->hs.size();
@@ -899,18 +933,37 @@ static int commit_impl(lk_engine *e, bool keep_state) {
   }
   HIPCHK(e->d_center.ensure((size_t)S));
   HIPCHK(hipMemcpy(e->d_center.p, e->h_center.data(), 2 * (size_t)S * sizeof(float), hipMemcpyHostToDevice));
-  HIPCHK(e->d_guess.ensure(6 * (size_t)S));
-  HIPCHK(e->d_last_p.ensure(6 * (size_t)S));
-  HIPCHK(e->d_prev_p.ensure(6 * (size_t)S));
-  HIPCHK(e->d_result.ensure((size_t)S));
-  HIPCHK(e->d_stats.ensure(4 * (size_t)S));
-  HIPCHK(e->d_last_eval_p.ensure(6 * (size_t)S));
-  if (!keep_state || S != e->S) {
-    HIPCHK(hipMemset(e->d_guess.p, 0, 6 * (size_t)S * sizeof(float)));
-    HIPCHK(hipMemset(e->d_last_p.p, 0, 6 * (size_t)S * sizeof(float)));
-    HIPCHK(hipMemset(e->d_prev_p.p, 0, 6 * (size_t)S * sizeof(float)));
-    HIPCHK(hipMemset(e->d_last_eval_p.p, 0, 6 * (size_t)S * sizeof(float)));
-    HIPCHK(hipMemset(e->d_stats.p, 0, 4 * (size_t)S * sizeof(uint32_t)));
+  // Per-sector sequence state (guess history, last record, last evaluated parameters) survives a
+  // commit for every sector that was not registered anew since the previous one: the reference's
+  // manager registers and solves sector after sector on the first frame (resetPolygon(i), then
+  // correlate(i): manager_class.cpp:340, :449) and moves them from their own records on the next
+  // (updatePolygon: cuda_polygon.cu:268-415), so a commit that adds sector i must not forget 0..i-1.
+  {
+    const size_t old = (size_t)std::min(e->S, S);
+    HIPCHK(e->d_guess.ensure_keep(6 * (size_t)S, 6 * old));
+    HIPCHK(e->d_last_p.ensure_keep(6 * (size_t)S, 6 * old));
+    HIPCHK(e->d_prev_p.ensure_keep(6 * (size_t)S, 6 * old));
+    HIPCHK(e->d_result.ensure_keep((size_t)S, old));
+    HIPCHK(e->d_stats.ensure_keep(4 * (size_t)S, 4 * old));
+    HIPCHK(e->d_last_eval_p.ensure_keep(6 * (size_t)S, 6 * old));
+    for (int s = 0; s < S;) { // zero the state of every run of fresh sectors
+      const bool fresh = (size_t)s >= old || (!keep_state && e->hs[(size_t)s].fresh);
+      int t = s + 1;
+      if (fresh) {
+        while (t < S && ((size_t)t >= old || (!keep_state && e->hs[(size_t)t].fresh)))
+          ++t;
+        const size_t n = (size_t)(t - s);
+        HIPCHK(hipMemset(e->d_guess.p + 6 * (size_t)s, 0, 6 * n * sizeof(float)));
+        HIPCHK(hipMemset(e->d_last_p.p + 6 * (size_t)s, 0, 6 * n * sizeof(float)));
+        HIPCHK(hipMemset(e->d_prev_p.p + 6 * (size_t)s, 0, 6 * n * sizeof(float)));
+        HIPCHK(hipMemset(e->d_last_eval_p.p + 6 * (size_t)s, 0, 6 * n * sizeof(float)));
+        HIPCHK(hipMemset(e->d_stats.p + 4 * (size_t)s, 0, 4 * n * sizeof(uint32_t)));
+        HIPCHK(hipMemset(e->d_result.p + (size_t)s, 0, n * sizeof(lk_result)));
+      }
+      s = t;
+    }
+    for (int s = 0; s < S; ++s)
+      e->hs[(size_t)s].fresh = false;
   }
   // size classes -> lanes per sector.  A class whose sectors are too few to fill the chip
   // (< 2048 wavefronts) and still large per lane is promoted to the next wider group.
@@ -952,7 +1005,7 @@ static int commit_impl(lk_engine *e, bool keep_state) {
   int force_team = 0;
   if (const char *f = std::getenv("LK_FORCE_TEAM")) { // test hook: every sector gets a team of this width
     force_team = std::atoi(f);
-    if (force_team > 1)
+    if (force_team >= 1) // (1: the team class's kernel with a single workgroup per sector)
       std::fill(e->h_class.begin(), e->h_class.end(), kTeamClass);
   }
   e->team_w = 0;
@@ -975,11 +1028,11 @@ static int commit_impl(lk_engine *e, bool keep_state) {
         n0_max = std::max(n0_max, e->hs[(size_t)s].n0());
       }
     if (n_team) {
-      int w = force_team > 1 ? force_team : (n0_max + kTeamMinSamples - 1) / kTeamMinSamples;
-      e->team_w = std::min(std::max(w, 2), kMaxTeam); // the launch clamps it to what is resident
-      e->team_min_samples = force_team > 1 ? 0 : kTeamMinSamples;
+      int w = force_team >= 1 ? force_team : (n0_max + kTeamMinSamples - 1) / kTeamMinSamples;
+      e->team_w = force_team == 1 ? 1 : std::min(std::max(w, 2), kMaxTeam); // the launch clamps it to what is resident
+      e->team_min_samples = force_team >= 1 ? 0 : kTeamMinSamples;
       HIPCHK(e->d_team_partials.ensure((size_t)n_team * 2 * (size_t)e->team_w * 32));
-      HIPCHK(e->d_team_arrivals.ensure((size_t)n_team));
+      HIPCHK(e->d_team_arrivals.ensure(2 * (size_t)n_team)); // arrival counters + broken flags
     }
   }
   e->h_order.clear();
@@ -1177,6 +1230,7 @@ int lk_translate_sectors(lk_engine *e, const float *offsets_xy, const float *cen
 // mean centres where the caller gives none; the host reads back only the per-level offsets
 // (starved-level bookkeeping).  LK_HOST_REWARP=1 keeps the host path (tests compare the two).
 static int rewarp_on_device(lk_engine *e, const float *centers_xy, const float *offsets_xy) {
+  Range range_("lk:rebuild moved lists");
   const int S = e->S;
   const lk_config &cfg = e->cfg;
   hipStream_t st = e->stream;
@@ -1564,6 +1618,10 @@ static int launch_groups(lk_engine *e, LkSolveArgs &a, int group, int c, int fir
 // Team workgroups wait for each other, so two team launches that are both only partly resident
 // would wait forever.  One engine never has two in flight; engines of one process take turns:
 // every team launch waits for the previous one on the same device (whoever issued it).
+static int team_fault_hook() { // LK_TEAM_FAULT=step (tests): a team workgroup goes missing -> the lone-workgroup fallback
+  const char *f = std::getenv("LK_TEAM_FAULT");
+  return f ? std::atoi(f) : 0;
+}
 static std::mutex g_team_mu;
 static hipEvent_t g_team_done[64] = {};
 
@@ -1580,6 +1638,7 @@ static int stale_iterations(lk_engine *e, lk_result *d_result, int n) {
 }
 
 static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
+  Range range_("lk:solve");
   if (e->timing)
     HIPCHK(hipEventRecord(e->ev_s0, e->stream));
   // Size classes are independent sector sets (own lists, counters and queue words): the first
@@ -1636,6 +1695,7 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
       a.team_min_samples = e->team_min_samples;
       a.team_partials = e->d_team_partials.p;
       a.team_arrivals = e->d_team_arrivals.p;
+      a.team_fault = team_fault_hook();
       if (e->team_w > 1 && e->cfg.device >= 0 && e->cfg.device < 64) {
         team_turn = std::unique_lock<std::mutex>(g_team_mu);
         team_done = &g_team_done[e->cfg.device];
@@ -1707,6 +1767,7 @@ int lk_correlate_all_async(lk_engine *e) {
 }
 
 int lk_wait_results(lk_engine *e, lk_result *out) {
+  Range range_("lk:gather records");
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
   if (!e->results_pending || !out)
@@ -1745,6 +1806,7 @@ int lk_correlate_all(lk_engine *e, const float *guesses, lk_result *out) {
   rc = launch_all(e, e->d_guess.p, e->d_result.p);
   if (rc)
     return rc;
+  Range range_("lk:gather records");
   HIPCHK(hipMemcpyAsync(out, e->d_result.p, (size_t)e->S * sizeof(lk_result), hipMemcpyDeviceToHost,
                         e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -1752,6 +1814,7 @@ int lk_correlate_all(lk_engine *e, const float *guesses, lk_result *out) {
 }
 
 int lk_correlate(lk_engine *e, int sector, float *guess_inout, lk_result *out) {
+  Range range_("lk:correlate one sector");
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
   if (!guess_inout || !out)
@@ -1803,6 +1866,7 @@ int lk_correlate(lk_engine *e, int sector, float *guess_inout, lk_result *out) {
     a.team_min_samples = e->team_min_samples;
     a.team_partials = e->d_team_partials.p;
     a.team_arrivals = e->d_team_arrivals.p;
+    a.team_fault = team_fault_hook();
     if (e->team_w > 1 && e->cfg.device >= 0 && e->cfg.device < 64) { // (see launch_all)
       team_turn = std::unique_lock<std::mutex>(g_team_mu);
       team_done = &g_team_done[e->cfg.device];

@@ -32,6 +32,8 @@
 #include <float.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 // Smallest pivot ratio d_j / A_jj the fast flavour factors through (below it the sector goes to
 // the SAFE kernel and the reference's QR).  1e-3 sent 0.4 % of config 4's solves there and, before
 // that pass existed, cost its 1 % tail a factor of ten against the reference; root-free Cholesky
@@ -342,13 +344,17 @@ __device__ __forceinline__ float rows_sum(float v) { // after row16_sum: add the
 // agent-scope release -> arrival counter; then one lane polls the counter (relaxed,
 // s_sleep, bounded), agent-scope acquire, workgroup barrier, and 29 lanes add up the
 // team's partial sums in a fixed order (deterministic).  Buffers alternate with the step
-// parity; a workgroup cannot be two steps ahead of its team.  All workgroups of a launch
-// are resident (the host caps the grid), so the wait always ends; the spin is bounded anyway.
+// parity; a workgroup cannot be two steps ahead of its team.  The host caps the grid at what is
+// resident, and every other kernel that may hold CU slots drains without waiting on anybody, so
+// the wait ends; should a workgroup still be missing after ~1 s (another process's kernels), the
+// team is marked broken and rank 0 solves the sector alone (see the kernel).
 struct TeamCtx {
   int w = 1, rank = 0, slot = 0, stride = 1; // stride: workgroups per slot in the partial-sum buffer
   uint32_t step = 0;
   float *partials = nullptr;
-  uint32_t *arrivals = nullptr;
+  uint32_t *arrivals = nullptr; // [n_sectors] arrival counters, then [n_sectors] "team is broken" flags
+  int n_slots = 0;
+  int fault = 0;                // test hook (LK_TEAM_FAULT): rank 1 never arrives at step `fault`
   bool timed_out = false;
 };
 
@@ -603,17 +609,26 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(team->arrivals + team->slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(team->fault && team->rank == 1 && (int)team->step == team->fault)) // (test hook: a workgroup goes missing)
+              __hip_atomic_fetch_add(team->arrivals + team->slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t target = team->step * (uint32_t)team_w;
+            uint32_t *broken = team->arrivals + team->n_slots + team->slot;
             bool ok = false;
-            // normally a few microseconds; ~1 s bound, and no second wait once the team is broken
-            for (int spin = 0; spin < (team->timed_out ? 0 : (1 << 20)); ++spin) {
+            // normally a few microseconds; ~1 s bound.  A workgroup that gives up marks the team
+            // broken for everybody (see the kernel: rank 0 then solves the sector on its own).
+            for (int spin = 0; spin < (1 << 20); ++spin) {
               if (__hip_atomic_load(team->arrivals + team->slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) {
                 ok = true;
                 break;
               }
+              if ((spin & 255) == 255 && __hip_atomic_load(broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+                break;
               __builtin_amdgcn_s_sleep(8);
             }
+            if (!ok)
+              __hip_atomic_store(broken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+              ok = __hip_atomic_load(broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             lds[0] = ok ? 0.f : 1.f;
@@ -1411,6 +1426,8 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
       team.slot = (int)blockIdx.x / a.team_w;
       team.partials = a.team_partials;
       team.arrivals = a.team_arrivals;
+      team.n_slots = a.n_sectors;
+      team.fault = a.team_fault;
       team.stride = a.team_w;
       // the team of a sector is as wide as its sample count is worth; the other workgroups
       // of its slot leave at once (uniform over the workgroup, before any barrier)
@@ -1519,7 +1536,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
       r.iterations = (ordered_all && k.n_evals == 1u && k.error != LK_ERROR_NONE && k.lg_chi == FLT_MAX && k.reached == 0)
                          ? kStaleIterations
                          : k.reached;
-      r.errorCode = team.timed_out ? (int)LK_ERROR_DEVICE : k.error;
+      r.errorCode = k.error;
       r.undCenterX = k.c0x;
       r.undCenterY = k.c0y;
       a.result[k.s] = r;
@@ -1778,6 +1795,21 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
     tr_eval += __builtin_amdgcn_s_memtime() - tr_e0;
     ++tr_steps;
 #endif
+    if constexpr (GROUP == 512) {
+      // A team whose workgroups did not all show up (a workgroup not resident for ~1 s: foreign
+      // kernels holding the GPU) is broken for good: its sums are incomplete.  Everybody but
+      // rank 0 leaves; rank 0 starts the sector again from its guess as a lone workgroup - the
+      // record is then the single-workgroup solve's, late instead of an error.
+      if (team.timed_out && team.w > 1) {
+        if (team.rank != 0)
+          return;
+        team.w = 1;
+        team.timed_out = false;
+        phase = PH_FETCH;
+        first_fetch = true;
+        continue;
+      }
+    }
     if (active) {
       Cold k = cold.load(cold_slot);
       float evaluated[6]; // the parameters this evaluation ran at (rescaled to level 0 only if the sector ends here)
@@ -2512,9 +2544,12 @@ template <class K> static int resident_workgroups(K kernel, int threads) {
 
 template <int MODEL, int INTERP, int GROUP, int THREADS, bool SAFE>
 static hipError_t launch_solve_gs(const LkSolveArgs &a, hipStream_t st) {
-  static int resident = 0; // per template instance (one device type per process)
-  if (resident == 0)
+  static std::atomic<int> resident_cache{0}; // per template instance (one device type per process); engines launch from several threads
+  int resident = resident_cache.load(std::memory_order_relaxed);
+  if (resident == 0) {
     resident = resident_workgroups(lk_solve_kernel<MODEL, INTERP, GROUP, THREADS, SAFE>, THREADS);
+    resident_cache.store(resident, std::memory_order_relaxed);
+  }
   const int per_wg = THREADS / GROUP;
   const int want = (a.n_sectors + per_wg - 1) / per_wg;
   LkSolveArgs b = a;
@@ -2553,7 +2588,7 @@ static hipError_t launch_solve_gs(const LkSolveArgs &a, hipStream_t st) {
     const int share = resident / (a.gpu_share > 1 ? a.gpu_share : 1);
     b.team_w = a.team_w < share / a.n_sectors ? a.team_w : share / a.n_sectors;
     if (b.team_w > 1) {
-      hipError_t te = hipMemsetAsync(a.team_arrivals, 0, (size_t)a.n_sectors * sizeof(uint32_t), st);
+      hipError_t te = hipMemsetAsync(a.team_arrivals, 0, 2 * (size_t)a.n_sectors * sizeof(uint32_t), st); // counters + broken flags
       if (te != hipSuccess)
         return te;
       b.persistent = 0;

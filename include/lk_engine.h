@@ -198,7 +198,11 @@ int lk_set_sector_blob(lk_engine *e, int sector, const float *contour_xy, int n_
 int lk_set_sector_points(lk_engine *e, int sector, const float *xy, int n, int use_center,
                          float cx, float cy);
 /* build per-level sample lists (pyramid_class.cpp:289-362) and upload; must be called
- * after the lk_set_sector_* calls and before lk_correlate_* */
+ * after the lk_set_sector_* calls and before lk_correlate_*.  Sectors registered since the
+ * previous commit start with zeroed sequence state (guess history, last record); every other
+ * sector keeps its state, so the reference's first-frame loop - resetPolygon(i), correlate(i),
+ * sector after sector (manager_class.cpp:340, :449) - can commit once per sector and still
+ * move every sector from its own record on the next frame (lk_update_sector). */
 int lk_commit_sectors(lk_engine *e);
 /* Domain tracking between the frames of a sequence, CPU-engine semantics (the CUDA engine's
  * cudaPolygon::updatePolygon, cuda_polygon.cu:268-415, moves by its own lastGood

@@ -1,0 +1,317 @@
+// lk_engine_mock.cpp - TEST INFRASTRUCTURE: a CPU stand-in for the subset of include/lk_engine.h
+// that include/lk_cuda_class_adapter.hpp calls, so that HipCudaClass can be EXECUTED in the build
+// container (no GPU) in the reference manager's exact call order.  It keeps the engine's
+// documented contracts (sectors must be committed before a solve; a commit keeps the state of
+// sectors that were not registered anew; lk_update_sector moves a sector by its own last record;
+// lk_correlate copies the result into the caller's guess) and journals every call.  The "solve"
+// is a closed-form fake: p = guess + 0.25 * (sector centre - image centre) / 100 on (u, v).
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "lk_engine.h"
+
+namespace {
+struct Sector {
+  int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
+  std::vector<float> xy;
+  bool set = false, fresh = true;
+  lk_result last{};
+  bool solved = false;
+};
+}
+struct lk_engine {
+  lk_config cfg{};
+  std::vector<Sector> hs;
+  bool committed = false;
+  int rows[3] = {0, 0, 0}, cols[3] = {0, 0, 0};
+  unsigned sum[3] = {0, 0, 0};
+  bool valid[3] = {false, false, false};
+  std::vector<float> guess, last_p, prev_p; // [S][6], engine-held (lk_adjust_initial_guess)
+  std::vector<lk_result> pending;
+  bool outstanding = false;
+  std::string err;
+};
+static std::string g_journal;
+static int g_commits = 0;
+static void J(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+#include <cstdarg>
+static void J(const char *fmt, ...) {
+  char b[256];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(b, sizeof b, fmt, ap);
+  va_end(ap);
+  static std::mutex mu; // lk_set_image(LK_IMG_NXT) may come from the caller's prefetch thread (lk_engine.h)
+  std::lock_guard<std::mutex> lock(mu);
+  g_journal += b;
+  g_journal += '\n';
+}
+
+extern "C" {
+const char *lk_mock_journal(void) { return g_journal.c_str(); }
+int lk_mock_commits(void) { return g_commits; }
+
+int lk_device_count(void) { return 1; }
+int lk_create(const lk_config *cfg, lk_engine **out) {
+  if (!cfg || !out)
+    return LK_ERROR_BAD_DOMAIN;
+  lk_engine *e = new lk_engine();
+  e->cfg = *cfg;
+  *out = e;
+  J("create interp=%d model=%d prec=%g iters=%d py=%d/%d/%d", cfg->interpolation, cfg->fitting_model, cfg->precision,
+    cfg->max_iters, cfg->py_start, cfg->py_step, cfg->py_stop);
+  return 0;
+}
+void lk_destroy(lk_engine *e) {
+  J("destroy");
+  delete e;
+}
+const char *lk_last_error_string(const lk_engine *e) { return e ? e->err.c_str() : "null"; }
+int lk_set_image(lk_engine *e, int slot, const uint8_t *px, int rows, int cols, int step) {
+  if (!e || slot < 0 || slot > 2 || !px)
+    return LK_ERROR_BAD_DOMAIN;
+  unsigned s = 0;
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c)
+      s = s * 31u + px[(size_t)r * step + c];
+  e->rows[slot] = rows, e->cols[slot] = cols, e->sum[slot] = s, e->valid[slot] = true;
+  J("set_image slot=%d %dx%d sum=%u", slot, rows, cols, s);
+  return 0;
+}
+int lk_rotate_und_from_def(lk_engine *e) {
+  e->sum[0] = e->sum[1], e->valid[0] = e->valid[1], e->valid[1] = false;
+  J("und_from_def");
+  return 0;
+}
+int lk_rotate_def_from_nxt(lk_engine *e) {
+  if (!e->valid[2])
+    return LK_ERROR_BAD_DOMAIN;
+  e->sum[1] = e->sum[2], e->valid[1] = true, e->valid[2] = false;
+  J("def_from_nxt");
+  return 0;
+}
+static Sector *slot(lk_engine *e, int s) {
+  if (s < 0)
+    return nullptr;
+  if ((size_t)s >= e->hs.size())
+    e->hs.resize((size_t)s + 1);
+  e->committed = false;
+  e->hs[(size_t)s].fresh = true;
+  return &e->hs[(size_t)s];
+}
+int lk_set_sector_rect(lk_engine *e, int s, int x0, int y0, int x1, int y1) {
+  Sector *q = slot(e, s);
+  if (!q || x1 < x0 || y1 < y0)
+    return LK_ERROR_BAD_DOMAIN;
+  q->x0 = x0, q->y0 = y0, q->x1 = x1, q->y1 = y1, q->set = true;
+  q->xy.clear();
+  J("set_rect %d [%d,%d]-[%d,%d]", s, x0, y0, x1, y1);
+  return 0;
+}
+int lk_set_sector_annular(lk_engine *e, int s, float r, float dr, float a, float da, float cx, float cy, int as) {
+  Sector *q = slot(e, s);
+  if (!q)
+    return LK_ERROR_BAD_DOMAIN;
+  q->xy = {cx + r, cy, cx + r + dr, cy};
+  q->set = true;
+  J("set_annular %d r=%g dr=%g a=%g da=%g c=(%g,%g) as=%d", s, r, dr, a, da, cx, cy, as);
+  return 0;
+}
+int lk_set_sector_blob(lk_engine *e, int s, const float *c, int n) {
+  Sector *q = slot(e, s);
+  if (!q || n < 3)
+    return LK_ERROR_BAD_DOMAIN;
+  q->xy.assign(c, c + 2 * n);
+  q->set = true;
+  J("set_blob %d n=%d", s, n);
+  return 0;
+}
+int lk_commit_sectors(lk_engine *e) {
+  for (auto &q : e->hs)
+    if (!q.set)
+      return LK_ERROR_BAD_DOMAIN;
+  for (auto &q : e->hs) {
+    if (q.fresh) {
+      q.last = lk_result{};
+      q.solved = false;
+    }
+    q.fresh = false;
+  }
+  e->committed = true;
+  ++g_commits;
+  J("commit S=%zu", e->hs.size());
+  return 0;
+}
+int lk_sector_count(const lk_engine *e) { return e ? (int)e->hs.size() : 0; }
+int lk_update_sector(lk_engine *e, int s, int mode) {
+  if (!e->committed || s < 0 || (size_t)s >= e->hs.size())
+    return LK_ERROR_BAD_DOMAIN;
+  Sector &q = e->hs[(size_t)s];
+  J("update %d mode=%d solved=%d u=%g v=%g", s, mode, (int)q.solved, q.last.resultingParameters[0], q.last.resultingParameters[1]);
+  if (mode == 1) { // Lagrangian: move by the rounded (u, v) of the sector's own last record
+    const int du = (int)(q.last.resultingParameters[0] + (q.last.resultingParameters[0] < 0 ? -0.5f : 0.5f));
+    const int dv = (int)(q.last.resultingParameters[1] + (q.last.resultingParameters[1] < 0 ? -0.5f : 0.5f));
+    q.x0 += du, q.x1 += du, q.y0 += dv, q.y1 += dv;
+  }
+  return 0;
+}
+static lk_result fake_solve(lk_engine *e, const Sector &q, const float *g) {
+  lk_result r{};
+  const float cx = 0.5f * (float)(q.x0 + q.x1), cy = 0.5f * (float)(q.y0 + q.y1);
+  for (int i = 0; i < 6; ++i)
+    r.resultingParameters[i] = g[i];
+  r.resultingParameters[0] += 0.0025f * (cx - 0.5f * (float)e->cols[0]);
+  r.resultingParameters[1] += 0.0025f * (cy - 0.5f * (float)e->rows[0]);
+  r.chi = 1.f + (float)(e->sum[1] % 97u);
+  r.numberOfPoints = (q.x1 - q.x0 + 1) * (q.y1 - q.y0 + 1);
+  r.iterations = 2;
+  r.errorCode = 0;
+  r.undCenterX = cx, r.undCenterY = cy;
+  return r;
+}
+int lk_correlate(lk_engine *e, int s, float *guess, lk_result *out) {
+  if (!e->committed || !e->valid[0] || !e->valid[1] || s < 0 || (size_t)s >= e->hs.size())
+    return LK_ERROR_BAD_DOMAIN;
+  float g[6] = {0, 0, 0, 0, 0, 0};
+  const int P = e->cfg.fitting_model == LK_FM_U ? 1 : e->cfg.fitting_model == LK_FM_UV ? 2 : e->cfg.fitting_model == LK_FM_UVQ ? 3 : 6;
+  for (int i = 0; i < P; ++i)
+    g[i] = guess[i];
+  Sector &q = e->hs[(size_t)s];
+  q.last = fake_solve(e, q, g);
+  q.solved = true;
+  *out = q.last;
+  for (int i = 0; i < P; ++i)
+    guess[i] = out->resultingParameters[i];
+  J("correlate %d guess=(%g,%g)", s, g[0], g[1]);
+  return 0;
+}
+int lk_correlate_all(lk_engine *e, const float *guesses, lk_result *out) {
+  if (!e->committed || !e->valid[0] || !e->valid[1])
+    return LK_ERROR_BAD_DOMAIN;
+  for (size_t s = 0; s < e->hs.size(); ++s) {
+    float g[6] = {0, 0, 0, 0, 0, 0};
+    if (guesses)
+      std::memcpy(g, guesses + 6 * s, sizeof g);
+    e->hs[s].last = out[s] = fake_solve(e, e->hs[s], g);
+    e->hs[s].solved = true;
+  }
+  e->last_p.resize(6 * e->hs.size(), 0.f);
+  for (size_t s = 0; s < e->hs.size(); ++s)
+    std::memcpy(&e->last_p[6 * s], out[s].resultingParameters, 6 * sizeof(float));
+  J("correlate_all S=%zu", e->hs.size());
+  return 0;
+}
+// ---- what lk_sequence_frame / lk_sequence_run (lk_tracker.cpp) call besides the above ----------
+int lk_clear_sectors(lk_engine *e) {
+  e->hs.clear();
+  e->committed = false;
+  J("clear");
+  return 0;
+}
+int lk_set_sectors_annular(lk_engine *e, int first, int count, const float *q, int as) {
+  for (int k = 0; k < count; ++k)
+    if (int rc = lk_set_sector_annular(e, first + k, q[6 * k], q[6 * k + 1], q[6 * k + 2], q[6 * k + 3], q[6 * k + 4], q[6 * k + 5], as))
+      return rc;
+  return 0;
+}
+int lk_translate_sectors(lk_engine *e, const float *off, const float *centers) {
+  if (!e->committed || !off)
+    return LK_ERROR_BAD_DOMAIN;
+  for (size_t s = 0; s < e->hs.size(); ++s) {
+    Sector &q = e->hs[s];
+    const int dx = (int)(off[2 * s] + 0.5f), dy = (int)(off[2 * s + 1] + 0.5f);
+    q.x0 += dx, q.x1 += dx, q.y0 += dy, q.y1 += dy;
+    for (size_t i = 0; i + 1 < q.xy.size(); i += 2)
+      q.xy[i] += (float)dx, q.xy[i + 1] += (float)dy;
+  }
+  J("translate S=%zu centers=%d", e->hs.size(), centers ? 1 : 0);
+  return 0;
+}
+int lk_rewarp_sectors(lk_engine *e, const float *centers) {
+  if (!e->committed)
+    return LK_ERROR_BAD_DOMAIN;
+  J("rewarp S=%zu centers=%d", e->hs.size(), centers ? 1 : 0);
+  return 0;
+}
+int lk_restore_sectors(lk_engine *e, int first) {
+  J("restore from %d", first);
+  return e->committed ? 0 : LK_ERROR_BAD_DOMAIN;
+}
+int lk_adjust_initial_guess(lk_engine *e, int frame, int cv, const float *gg, float gcx, float gcy) {
+  if (!e->committed)
+    return LK_ERROR_BAD_DOMAIN;
+  const size_t S = e->hs.size();
+  e->guess.assign(6 * S, 0.f);
+  e->last_p.resize(6 * S, 0.f);
+  e->prev_p.resize(6 * S, 0.f);
+  for (size_t s = 0; s < S; ++s)
+    for (int i = 0; i < 6; ++i) {
+      float g;
+      if (frame == 0) {
+        g = gg ? gg[i] : 0.f;
+        e->prev_p[6 * s + i] = g;
+      } else {
+        const float r = e->last_p[6 * s + i], q = e->prev_p[6 * s + i];
+        g = cv ? r + (r - q) : r;
+        e->prev_p[6 * s + i] = r;
+      }
+      e->guess[6 * s + i] = g;
+    }
+  (void)gcx, (void)gcy;
+  J("adjust_guess frame=%d cv=%d", frame, cv);
+  return 0;
+}
+int lk_get_guesses(lk_engine *e, float *g) {
+  std::memcpy(g, e->guess.data(), e->guess.size() * sizeof(float));
+  return 0;
+}
+int lk_correlate_all_async(lk_engine *e) {
+  if (!e->committed || e->outstanding || !e->valid[0] || !e->valid[1])
+    return LK_ERROR_BAD_DOMAIN;
+  const size_t S = e->hs.size();
+  if (e->guess.size() != 6 * S)
+    e->guess.assign(6 * S, 0.f);
+  e->pending.resize(S);
+  e->last_p.resize(6 * S, 0.f);
+  for (size_t s = 0; s < S; ++s) {
+    e->pending[s] = e->hs[s].last = fake_solve(e, e->hs[s], &e->guess[6 * s]);
+    e->hs[s].solved = true;
+    std::memcpy(&e->last_p[6 * s], e->pending[s].resultingParameters, 6 * sizeof(float));
+  }
+  e->outstanding = true;
+  J("correlate_all_async S=%zu", S);
+  return 0;
+}
+int lk_wait_results(lk_engine *e, lk_result *out) {
+  if (!e->outstanding || !out)
+    return LK_ERROR_BAD_DOMAIN;
+  std::memcpy(out, e->pending.data(), e->pending.size() * sizeof(lk_result));
+  e->outstanding = false;
+  return 0;
+}
+
+int lk_get_und_xy(lk_engine *e, int s, float *xy, int cap, int *count) {
+  if (s < 0 || (size_t)s >= e->hs.size() || !e->hs[(size_t)s].set)
+    return LK_ERROR_BAD_DOMAIN;
+  const Sector &q = e->hs[(size_t)s];
+  std::vector<float> v = q.xy;
+  if (v.empty())
+    for (int x = q.x0; x <= q.x1; ++x)
+      for (int y = q.y0; y <= q.y1; ++y)
+        v.push_back((float)x), v.push_back((float)y);
+  *count = (int)(v.size() / 2);
+  for (int i = 0; i < *count && i < cap; ++i)
+    xy[2 * i] = v[2 * (size_t)i], xy[2 * i + 1] = v[2 * (size_t)i + 1];
+  return 0;
+}
+int lk_get_def_xy(lk_engine *e, int s, const float *p, float *xy, int cap, int *count) {
+  int rc = lk_get_und_xy(e, s, xy, cap, count);
+  if (!rc && p)
+    for (int i = 0; i < *count && i < cap; ++i)
+      xy[2 * i] += p[0], xy[2 * i + 1] += p[1];
+  return rc;
+}
+}

@@ -802,6 +802,76 @@ def test_team_of_workgroups_per_sector(oracle, speckle512, width, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_broken_team_falls_back_to_one_workgroup(speckle512, monkeypatch):
+    """A team workgroup that never shows up (LK_TEAM_FAULT: rank 1 skips its arrival at step 3 - in
+    production: a workgroup that is not resident because foreign kernels hold the GPU) must not
+    cost the sector: the waiting workgroups give up after ~1 s, mark the team broken, and rank 0
+    solves the sector again on its own.  The record is the single-workgroup solve's, bit for bit."""
+    rects = [(40, 40, 250, 250), (260, 40, 470, 260)]
+
+    def run():
+        e = ca.HipCorrelationEngine()
+        e.set_undeformed_image(speckle512[0])
+        e.set_deformed_image(speckle512[1])
+        for s, r in enumerate(rects):
+            e.resetPolygon_rect(s, *r)
+        e.commit_sectors()
+        got = e.correlate_all(np.zeros(6, np.float32))
+        e.close()
+        return got
+
+    monkeypatch.setenv("LK_FORCE_TEAM", "1")        # one 8-wavefront workgroup per sector
+    alone = run()
+    monkeypatch.setenv("LK_FORCE_TEAM", "4")
+    healthy = run()
+    monkeypatch.setenv("LK_TEAM_FAULT", "3")
+    broken = run()
+    assert (alone["error_code"] == 0).all() and (broken["error_code"] == 0).all()
+    assert broken.tobytes() == alone.tobytes()
+    assert healthy.tobytes() != alone.tobytes() and np.abs(healthy["p"] - alone["p"]).max() < 2e-5
+
+
+@pytest.mark.gpu
+def test_team_solve_with_foreign_kernels_in_flight(speckle512, monkeypatch):
+    """Team launches assume their workgroups become resident; kernels of other streams (here: another
+    engine's persistent non-team solves, queued back to back on its own stream - the shape RCCL
+    kernels or a second engine have) may hold CU slots meanwhile.  They drain without waiting on
+    anybody, so the team only starts later: same records as the lone team solve."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipStreamCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+    hip.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    und, dfm = speckle512
+    st = ctypes.c_void_p()
+    assert hip.hipStreamCreateWithFlags(ctypes.byref(st), 1) == 0
+    noisy = ca.HipCorrelationEngine()               # 57 600 small sectors: a persistent grid that fills every CU
+    noisy.set_stream(st.value)
+    noisy.set_undeformed_image(und)
+    noisy.set_deformed_image(dfm)
+    noisy.set_rect_grid(16.0, 16.0, 495.0, 495.0, 240, 240)
+    noisy.commit_sectors()
+    monkeypatch.setenv("LK_FORCE_TEAM", "6")
+    e = ca.HipCorrelationEngine()
+    e.set_undeformed_image(und)
+    e.set_deformed_image(dfm)
+    for s, (x0, y0) in enumerate(((40, 40), (260, 50), (60, 270), (250, 260))):
+        e.resetPolygon_rect(s, x0, y0, x0 + 200, y0 + 190)
+    e.commit_sectors()
+    want = e.correlate_all(np.zeros(6, np.float32))
+    assert (want["error_code"] == 0).all()
+    for rep in range(3):
+        for _ in range(4):
+            noisy.adjust_initial_guess(0, False, np.zeros(6, np.float32), (256.0, 256.0))
+            noisy.correlate_all_async()
+            got = e.correlate_all(np.zeros(6, np.float32))   # runs while the other stream's solve is on the GPU
+            assert got.tobytes() == want.tobytes(), rep
+            noisy.wait_results()
+    noisy.close()
+    e.close()
+    assert hip.hipStreamDestroy(st) == 0
+
+
+@pytest.mark.gpu
 def test_solo_half_wavefronts(oracle, speckle512, monkeypatch):
     """32-lane groups: a half-wavefront that has run out of work joins its partner's sector
     ("solo").  Same parity bars as everything else; against the
