@@ -162,6 +162,58 @@ def other_configs(ca):
     return out
 
 
+def native_group_bench(args, ca, wl):
+    """`bench.py --native --gpus N` (ONE process): the same step through include/lk_group.h - frames enter on
+    device 0, travel by ncclBroadcast, every device solves its contiguous block of the sector grid (strong
+    scaling: one grid shared by all devices), records come back by ncclAllGather.  Same JSON contract."""
+    import torch
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise SystemExit("--native is the single-process path: run it without torch.distributed.run")
+    n = args.gpus
+    und, dfm = ca.speckle.speckle_pair(wl.size, wl.size, p=wl.truth if wl.size <= 2048 else (1.3, -0.7, 0.0005, 0.0, 0.0, -0.00025),
+                                       seed=7 if wl.size <= 2048 else 13, device="cuda:0" if wl.size > 2048 else None)
+    d_und, d_def = torch.from_numpy(und).to("cuda:0"), torch.from_numpy(dfm).to("cuda:0")
+    torch.cuda.synchronize()
+    g = ca.HipCorrelationGroup(n, fitting_model=wl.model, py_stop=wl.py_stop)
+    g.for_each_engine("lk_set_timing", 0)
+    g.set_image_device(ca.IMG_UND, d_und.data_ptr(), wl.size, wl.size)
+    g.set_image_device(ca.IMG_DEF, d_def.data_ptr(), wl.size, wl.size)
+    g.set_rect_grid(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, wl.hs, wl.vs)
+    g.commit_sectors()
+
+    def step():
+        g.set_image_device(ca.IMG_UND, d_und.data_ptr(), wl.size, wl.size)   # broadcast + pyramid on every device
+        g.set_image_device(ca.IMG_DEF, d_def.data_ptr(), wl.size, wl.size)
+        g.correlate_all(None, fetch=False)                                   # solve + all-gather, records stay in HBM
+
+    for _ in range(args.warmup):
+        step()
+    g.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    g.synchronize()
+    dt = time.perf_counter() - t0
+    g.for_each_engine("lk_set_timing", 1)
+    res = g.correlate_all(None)
+    st = g.stats()
+    S = g.n_sectors
+    line = {"metric": "correlation-point-iterations/sec", "value": st["point_iterations"] * args.steps / dt,
+            "unit": "point-iterations/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl.name, "sectors_total": S, "parallelism": f"lk_group: one process, {n} device(s), "
+                       "one host thread + HIP stream per device, ncclBroadcast of frames, ncclAllGather of records",
+                       "step": "broadcast + pyramid(und) + pyramid(def) on every device, sharded solve, record all-gather"},
+            "roofline": {"bound": "hbm", "achieved": st["algorithmic_bytes"] / (st["solve_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS * n,
+                         "unit": "GB/s", "frac": st["algorithmic_bytes"] / (st["solve_ms"] * 1e-3) / 1e9 / (HBM_PEAK_GBS * n),
+                         "traffic": None, "kernel": "lk_solve_kernel, slowest member's engine-timed solve of one step",
+                         "kernel_ms": st["solve_ms"], "algorithmic_bytes_per_launch": st["algorithmic_bytes"]},
+            "per_pair": {"point_iterations": st["point_iterations"], "error_free_fraction": float((res["error_code"] == 0).mean())}}
+    print(json.dumps(line))
+    g.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,6 +231,9 @@ def main():
                          "all-gather (the host cost of a collective exceeds a step's GPU time)")
     ap.add_argument("--overlap", type=int, default=3,
                     help="N = 1: pairs in flight of the extra `overlapped` block (0: skip it)")
+    ap.add_argument("--native", action="store_true",
+                    help="single process, no torch.distributed: the C-ABI group (include/lk_group.h) drives --gpus devices "
+                         "with one host thread + stream each, ncclBroadcast of frames, ncclAllGather of records")
     ap.add_argument("--workload", default="C2", choices=["C2", "C4", "C4B", "C5"],
                     help="C2 (default, the headline: weak scaling, every rank its own 10k-sector grid); "
                          "C4 / C4B / C5: ONE pair of that config with its sector grid sharded over the ranks "
@@ -189,6 +244,8 @@ def main():
     import correlation_amd as ca
     from correlation_amd.workload import C2, C4, C4B, C5, shard_range
 
+    if args.native:
+        return native_group_bench(args, ca, {"C2": C2, "C4": C4, "C4B": C4B, "C5": C5}[args.workload])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -12,3 +12,4 @@ from ._ffi import (ERROR_BAD_DOMAIN, ERROR_CORRELATION_MAX_ITERS_REACHED, ERROR_
 from .engine import HipCorrelationEngine, LkError  # noqa: F401
 from . import speckle  # noqa: F401
 from . import tracker  # noqa: F401
+from .group import HipCorrelationGroup  # noqa: F401

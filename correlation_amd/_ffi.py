@@ -120,12 +120,53 @@ SYMBOLS = {
                                           _F, C.c_int64]),
     "lk_roi_blob_points": (C.c_int64, [_F, C.c_int, _F, C.c_int64]),
     "lk_roi_decimate": (C.c_int, [_F, C.c_int, C.c_int, _F]),
+    # include/lk_group.h
+    "lk_group_create": (C.c_int, [C.POINTER(LkConfig), C.c_int, _I, C.POINTER(_P)]),
+    "lk_group_destroy": (None, [_P]),
+    "lk_group_last_error_string": (C.c_char_p, [_P]),
+    "lk_group_size": (C.c_int, [_P]),
+    "lk_group_engine": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "lk_group_shard": (C.c_int, [_P, C.c_int, _I, _I]),
+    "lk_group_shard_range": (C.c_int, [C.c_int, C.c_int, C.c_int, _I, _I]),
+    "lk_group_set_image": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
+    "lk_group_set_image_device": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
+    "lk_group_rotate_und_from_def": (C.c_int, [_P]),
+    "lk_group_rotate_def_from_nxt": (C.c_int, [_P]),
+    "lk_group_clear_sectors": (C.c_int, [_P]),
+    "lk_group_set_sector_rect": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "lk_group_set_rect_grid": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]),
+    "lk_group_set_sector_annular": (C.c_int, [_P, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                              C.c_float, C.c_int]),
+    "lk_group_set_sector_points": (C.c_int, [_P, C.c_int, _F, C.c_int, C.c_int, C.c_float, C.c_float]),
+    "lk_group_commit_sectors": (C.c_int, [_P]),
+    "lk_group_sector_count": (C.c_int, [_P]),
+    "lk_group_correlate_all": (C.c_int, [_P, _F, _P]),
+    "lk_group_adjust_initial_guess": (C.c_int, [_P, C.c_int, C.c_int, _F, C.c_float, C.c_float]),
+    "lk_group_records_device": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "lk_group_block_records": (C.c_int, [_P]),
+    "lk_group_synchronize": (C.c_int, [_P]),
+    "lk_group_get_stats": (C.c_int, [_P, C.POINTER(LkStats)]),
     "lk_load_pgm": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), _I, _I]),
     "lk_free_image": (None, [C.POINTER(C.c_uint8)]),
 }
 
 
+def _load_torch_first():
+    """PyTorch wheels bundle their own ROCm runtime (libamdhip64, libhsa-runtime64, librccl, libroctx64).
+    A process that loads the system copies first (through liblk_engine.so) and torch's copies later has
+    two HSA runtimes, and the one that comes second finds no GPU ("No HIP GPUs are available").  With
+    torch imported first both resolve to the same copies.  Python harness only: a C/C++ consumer of the
+    library links the system ROCm and never meets torch.  LK_NO_TORCH_PRELOAD=1 skips it."""
+    if os.environ.get("LK_NO_TORCH_PRELOAD"):
+        return
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def load_library(path=LIB_PATH):
+    _load_torch_first()
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is missing: the HIP engine is the product and there is no fallback. "

@@ -9,9 +9,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblk_engine.so")
-SOURCES = ["lk_engine.cpp", "lk_tracker.cpp", "lk_kernels.hip"]
+SOURCES = ["lk_engine.cpp", "lk_tracker.cpp", "lk_group.cpp", "lk_kernels.hip"]
 HEADERS = ["lk_device.hpp", "lk_roi.hpp", os.path.join("..", "..", "include", "lk_engine.h"),
-           os.path.join("..", "..", "include", "lk_tracker.h")]
+           os.path.join("..", "..", "include", "lk_tracker.h"), os.path.join("..", "..", "include", "lk_group.h")]
 
 
 def hipcc_path():
@@ -44,6 +44,7 @@ def build(force=False, verbose=False):
         "-Wall", "-Wextra", "-o", LIB,
     ] + os.environ.get("LK_EXTRA_HIPCC_FLAGS", "").split() + SOURCES + [  # (tuning experiments)
         "-lrocprofiler-sdk-roctx",   # roctx ranges (lk_engine.cpp: struct Range)
+        "-lrccl",                    # lk_group.cpp: ncclBroadcast / ncclAllGather over xGMI
     ]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

@@ -1,0 +1,558 @@
+// lk_group.cpp - single-process multi-GPU engine behind include/lk_group.h: one lk_engine, one host
+// thread and one HIP stream per device; sectors in contiguous blocks of the global index; frames
+// by ncclBroadcast, records by ncclAllGather (RCCL over xGMI).  SURVEY.md section 8(e).
+//
+// Threads.  Every entry point hands ONE job to all member threads and waits for them (the jobs
+// are a few asynchronous enqueues each; what takes time runs on the devices).  Inside a job every
+// member issues the same sequence of RCCL calls on its own communicator and stream - the
+// one-thread-per-device model of ncclCommInitAll - so the collectives rendezvous without
+// ncclGroupStart/End.  No host thread ever waits for another one inside a job, except in the
+// one-GPU rehearsal mode (the same device listed several times), where device-to-device copies
+// and a host barrier stand in for the two collectives.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/lk_group.h"
+
+namespace {
+
+struct SectorSpec { // what lk_group_set_sector_* recorded, replayed on the owner at commit
+  int kind = 0;     // 0 unset, 1 rect, 2 annular, 3 points
+  int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+  float r = 0, dr = 0, a = 0, da = 0, cx = 0, cy = 0;
+  int as = 1, use_center = 0;
+  std::vector<float> xy;
+};
+
+struct Member {
+  int rank = 0, device = 0;
+  lk_engine *e = nullptr;
+  hipStream_t st = nullptr;
+  ncclComm_t comm = nullptr;
+  uint8_t *d_frame[3] = {nullptr, nullptr, nullptr}; // level-0 pixels of the slots, dense rows
+  size_t frame_cap[3] = {0, 0, 0};
+  float *d_guess = nullptr;   // [cap][6]
+  lk_result *d_rec = nullptr; // [cap] this member's block (padded)
+  lk_result *d_all = nullptr; // [n][cap] everybody's blocks
+  size_t cap = 0;
+  int first = 0, count = 0;
+  std::thread th;
+};
+
+} // namespace
+
+struct lk_group {
+  lk_config cfg{};
+  std::vector<Member> m;
+  bool loopback = false; // duplicate devices: copies + host barrier instead of RCCL (rehearsal on one GPU)
+  // sector registry (global index)
+  std::vector<SectorSpec> secs;
+  bool grid = false;
+  float gx0 = 0, gy0 = 0, gx1 = 0, gy1 = 0;
+  int ghs = 0, gvs = 0;
+  int S = 0, cap = 0;
+  bool committed = false;
+  // job hand-off
+  std::mutex mu;
+  std::condition_variable cv_job, cv_done;
+  unsigned long long gen = 0;
+  int pending = 0;
+  bool quit = false;
+  std::function<int(Member &)> job;
+  std::vector<int> rc;
+  std::vector<std::string> msg;
+  // rehearsal-mode barrier between the member threads
+  std::mutex bmu;
+  std::condition_variable bcv;
+  int barrier_count = 0;
+  unsigned long long barrier_gen = 0;
+  std::string err;
+
+  int fail(int code, const std::string &what) {
+    err = what;
+    return code;
+  }
+  void barrier() {
+    std::unique_lock<std::mutex> lock(bmu);
+    const unsigned long long g0 = barrier_gen;
+    if (++barrier_count == (int)m.size()) {
+      barrier_count = 0;
+      ++barrier_gen;
+      bcv.notify_all();
+    } else {
+      bcv.wait(lock, [&] { return barrier_gen != g0; });
+    }
+  }
+  // run `f` on every member thread; returns the first error
+  int run(std::function<int(Member &)> f) {
+    std::unique_lock<std::mutex> lock(mu);
+    job = std::move(f);
+    std::fill(rc.begin(), rc.end(), 0);
+    pending = (int)m.size();
+    ++gen;
+    cv_job.notify_all();
+    cv_done.wait(lock, [&] { return pending == 0; });
+    for (size_t i = 0; i < m.size(); ++i)
+      if (rc[i]) {
+        err = "rank " + std::to_string(i) + ": " + msg[i];
+        return rc[i];
+      }
+    return LK_ERROR_NONE;
+  }
+};
+
+namespace {
+
+void shard(int S, int rank, int n, int &first, int &count) { // [r*S/G, (r+1)*S/G)
+  first = (int)((long long)S * rank / n);
+  count = (int)((long long)S * (rank + 1) / n) - first;
+}
+
+void worker(lk_group *g, int rank) {
+  Member &me = g->m[(size_t)rank];
+  unsigned long long seen = 0;
+  for (;;) {
+    std::function<int(Member &)> f;
+    {
+      std::unique_lock<std::mutex> lock(g->mu);
+      g->cv_job.wait(lock, [&] { return g->quit || g->gen != seen; });
+      if (g->quit)
+        return;
+      seen = g->gen;
+      f = g->job;
+    }
+    int r = hipSetDevice(me.device) == hipSuccess ? f(me) : LK_ERROR_DEVICE;
+    {
+      std::unique_lock<std::mutex> lock(g->mu);
+      g->rc[(size_t)rank] = r;
+      if (--g->pending == 0)
+        g->cv_done.notify_all();
+    }
+  }
+}
+
+// error plumbing inside jobs
+#define GHIP(call)                                                                                   \
+  do {                                                                                               \
+    hipError_t _e = (call);                                                                          \
+    if (_e != hipSuccess) {                                                                          \
+      g->msg[(size_t)me.rank] = std::string(#call) + ": " + hipGetErrorString(_e);                   \
+      return LK_ERROR_DEVICE;                                                                        \
+    }                                                                                                \
+  } while (0)
+#define GNCCL(call)                                                                                  \
+  do {                                                                                               \
+    ncclResult_t _e = (call);                                                                        \
+    if (_e != ncclSuccess) {                                                                         \
+      g->msg[(size_t)me.rank] = std::string(#call) + ": " + ncclGetErrorString(_e);                  \
+      return LK_ERROR_DEVICE;                                                                        \
+    }                                                                                                \
+  } while (0)
+#define GLK(call)                                                                                    \
+  do {                                                                                               \
+    int _e = (call);                                                                                 \
+    if (_e != LK_ERROR_NONE) {                                                                       \
+      g->msg[(size_t)me.rank] = std::string(#call) + ": " + lk_last_error_string(me.e);              \
+      return _e;                                                                                     \
+    }                                                                                                \
+  } while (0)
+
+int ensure_frame(lk_group *g, Member &me, int slot, size_t bytes) {
+  if (me.frame_cap[slot] >= bytes)
+    return LK_ERROR_NONE;
+  // readers of the old buffer: the pyramid kernel of the previous frame (the next-frame slot's runs
+  // on the engine's own next-frame stream)
+  GLK(lk_synchronize(me.e));
+  if (me.d_frame[slot])
+    GHIP(hipFree(me.d_frame[slot]));
+  me.d_frame[slot] = nullptr;
+  me.frame_cap[slot] = 0;
+  GHIP(hipMalloc((void **)&me.d_frame[slot], bytes));
+  me.frame_cap[slot] = bytes;
+  return LK_ERROR_NONE;
+}
+
+// pixels are in rank 0's d_frame[slot]: send them to everybody and build the pyramids
+int distribute_frame(lk_group *g, Member &me, int slot, int rows, int cols) {
+  const size_t bytes = (size_t)rows * (size_t)cols;
+  if (!g->loopback) {
+    GNCCL(ncclBroadcast(me.d_frame[slot], me.d_frame[slot], bytes, ncclUint8, 0, me.comm, me.st));
+  } else if (g->m.size() > 1) {
+    if (me.rank == 0)
+      GHIP(hipStreamSynchronize(me.st));
+    g->barrier(); // rank 0's pixels are there
+    if (me.rank != 0) {
+      GHIP(hipMemcpyAsync(me.d_frame[slot], g->m[0].d_frame[slot], bytes, hipMemcpyDeviceToDevice, me.st));
+      GHIP(hipStreamSynchronize(me.st));
+    }
+    g->barrier(); // nobody reads rank 0's buffer any more
+  }
+  if (slot == LK_IMG_NXT) // the engine fills that slot on its own next-frame stream: the pixels must have arrived
+    GHIP(hipStreamSynchronize(me.st));
+  GLK(lk_set_image_device(me.e, slot, me.d_frame[slot], rows, cols, cols));
+  return LK_ERROR_NONE;
+}
+
+} // namespace
+
+extern "C" {
+
+int lk_group_create(const lk_config *cfg, int n_devices, const int *devices, lk_group **out) {
+  if (!cfg || !out || n_devices < 1 || n_devices > 64)
+    return LK_ERROR_BAD_DOMAIN;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return LK_ERROR_DEVICE; // no silent CPU fallback
+  lk_group *g = new lk_group();
+  g->cfg = *cfg;
+  g->m.resize((size_t)n_devices);
+  g->rc.assign((size_t)n_devices, 0);
+  g->msg.assign((size_t)n_devices, std::string());
+  std::vector<int> devs((size_t)n_devices);
+  for (int r = 0; r < n_devices; ++r) {
+    devs[(size_t)r] = devices ? devices[r] : r;
+    if (devs[(size_t)r] < 0 || devs[(size_t)r] >= ndev) {
+      delete g;
+      return LK_ERROR_DEVICE;
+    }
+    for (int q = 0; q < r; ++q)
+      g->loopback = g->loopback || devs[(size_t)q] == devs[(size_t)r];
+  }
+  bool ok = true;
+  for (int r = 0; r < n_devices && ok; ++r) {
+    Member &me = g->m[(size_t)r];
+    me.rank = r;
+    me.device = devs[(size_t)r];
+    lk_config c = *cfg;
+    c.device = me.device;
+    ok = lk_create(&c, &me.e) == LK_ERROR_NONE && hipSetDevice(me.device) == hipSuccess &&
+         hipStreamCreateWithFlags(&me.st, hipStreamNonBlocking) == hipSuccess &&
+         lk_set_stream(me.e, me.st) == LK_ERROR_NONE;
+  }
+  if (ok && !g->loopback) {
+    std::vector<ncclComm_t> comms((size_t)n_devices);
+    ok = ncclCommInitAll(comms.data(), n_devices, devs.data()) == ncclSuccess;
+    if (ok)
+      for (int r = 0; r < n_devices; ++r)
+        g->m[(size_t)r].comm = comms[(size_t)r];
+  }
+  if (!ok) {
+    lk_group_destroy(g);
+    return LK_ERROR_DEVICE;
+  }
+  for (int r = 0; r < n_devices; ++r)
+    g->m[(size_t)r].th = std::thread(worker, g, r);
+  *out = g;
+  return LK_ERROR_NONE;
+}
+
+void lk_group_destroy(lk_group *g) {
+  if (!g)
+    return;
+  {
+    std::unique_lock<std::mutex> lock(g->mu);
+    g->quit = true;
+    g->cv_job.notify_all();
+  }
+  for (Member &me : g->m) {
+    if (me.th.joinable())
+      me.th.join();
+    (void)hipSetDevice(me.device);
+    if (me.e)
+      (void)lk_synchronize(me.e);
+    if (me.comm)
+      (void)ncclCommDestroy(me.comm);
+    for (uint8_t *p : me.d_frame)
+      if (p)
+        (void)hipFree(p);
+    for (void *p : {(void *)me.d_guess, (void *)me.d_rec, (void *)me.d_all})
+      if (p)
+        (void)hipFree(p);
+    if (me.e)
+      lk_destroy(me.e);
+    if (me.st)
+      (void)hipStreamDestroy(me.st);
+  }
+  delete g;
+}
+
+const char *lk_group_last_error_string(const lk_group *g) { return g ? g->err.c_str() : "null group"; }
+int lk_group_size(const lk_group *g) { return g ? (int)g->m.size() : 0; }
+
+int lk_group_engine(lk_group *g, int rank, lk_engine **e) {
+  if (!g || !e || rank < 0 || rank >= (int)g->m.size())
+    return LK_ERROR_BAD_DOMAIN;
+  *e = g->m[(size_t)rank].e;
+  return LK_ERROR_NONE;
+}
+
+int lk_group_shard_range(int n_sectors, int rank, int n_ranks, int *first, int *count) {
+  if (n_sectors < 0 || n_ranks < 1 || rank < 0 || rank >= n_ranks || !first || !count)
+    return LK_ERROR_BAD_DOMAIN;
+  shard(n_sectors, rank, n_ranks, *first, *count);
+  return LK_ERROR_NONE;
+}
+
+int lk_group_shard(const lk_group *g, int rank, int *first, int *count) {
+  if (!g || rank < 0 || rank >= (int)g->m.size() || !first || !count)
+    return LK_ERROR_BAD_DOMAIN;
+  const int S = g->committed ? g->S : (g->grid ? g->ghs * g->gvs : (int)g->secs.size());
+  shard(S, rank, (int)g->m.size(), *first, *count);
+  return LK_ERROR_NONE;
+}
+
+// ---- images -------------------------------------------------------------------------------------
+static int set_image_any(lk_group *g, int slot, const void *src, bool on_device0, int rows, int cols, int step) {
+  if (!g)
+    return LK_ERROR_BAD_DOMAIN;
+  if (slot < 0 || slot > 2 || !src || rows < 1 || cols < 1 || step < cols)
+    return g->fail(LK_ERROR_BAD_DOMAIN, "lk_group_set_image: bad arguments");
+  return g->run([=](Member &me) -> int {
+    if (int rc = ensure_frame(g, me, slot, (size_t)rows * (size_t)cols))
+      return rc;
+    if (me.rank == 0)
+      GHIP(hipMemcpy2DAsync(me.d_frame[slot], (size_t)cols, src, (size_t)step, (size_t)cols, (size_t)rows,
+                            on_device0 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, me.st));
+    return distribute_frame(g, me, slot, rows, cols);
+  });
+}
+int lk_group_set_image(lk_group *g, int slot, const uint8_t *host_pixels, int rows, int cols, int step) {
+  return set_image_any(g, slot, host_pixels, false, rows, cols, step);
+}
+int lk_group_set_image_device(lk_group *g, int slot, const void *device0_pixels, int rows, int cols, int step) {
+  return set_image_any(g, slot, device0_pixels, true, rows, cols, step);
+}
+int lk_group_rotate_und_from_def(lk_group *g) {
+  if (!g)
+    return LK_ERROR_BAD_DOMAIN;
+  return g->run([=](Member &me) -> int {
+    GLK(lk_rotate_und_from_def(me.e));
+    return LK_ERROR_NONE;
+  });
+}
+int lk_group_rotate_def_from_nxt(lk_group *g) {
+  if (!g)
+    return LK_ERROR_BAD_DOMAIN;
+  return g->run([=](Member &me) -> int {
+    GLK(lk_rotate_def_from_nxt(me.e));
+    return LK_ERROR_NONE;
+  });
+}
+
+// ---- sectors ------------------------------------------------------------------------------------
+int lk_group_clear_sectors(lk_group *g) {
+  if (!g)
+    return LK_ERROR_BAD_DOMAIN;
+  g->secs.clear();
+  g->grid = false;
+  g->committed = false;
+  g->S = 0;
+  return LK_ERROR_NONE;
+}
+static SectorSpec *spec_slot(lk_group *g, int sector) {
+  if (!g || sector < 0)
+    return nullptr;
+  if (g->grid) { // a grid is replaced by individually registered sectors
+    g->grid = false;
+    g->secs.clear();
+  }
+  if ((size_t)sector >= g->secs.size())
+    g->secs.resize((size_t)sector + 1);
+  g->committed = false;
+  return &g->secs[(size_t)sector];
+}
+int lk_group_set_sector_rect(lk_group *g, int sector, int x0, int y0, int x1, int y1) {
+  SectorSpec *s = spec_slot(g, sector);
+  if (!s || x1 < x0 || y1 < y0)
+    return g ? g->fail(LK_ERROR_BAD_DOMAIN, "lk_group_set_sector_rect: bad rectangle") : LK_ERROR_BAD_DOMAIN;
+  *s = SectorSpec();
+  s->kind = 1, s->x0 = x0, s->y0 = y0, s->x1 = x1, s->y1 = y1;
+  return LK_ERROR_NONE;
+}
+int lk_group_set_rect_grid(lk_group *g, float x_begin, float y_begin, float x_end, float y_end, int hs, int vs) {
+  if (!g || hs < 1 || vs < 1)
+    return g ? g->fail(LK_ERROR_BAD_DOMAIN, "lk_group_set_rect_grid: bad subdivision") : LK_ERROR_BAD_DOMAIN;
+  g->secs.clear();
+  g->grid = true;
+  g->gx0 = x_begin, g->gy0 = y_begin, g->gx1 = x_end, g->gy1 = y_end, g->ghs = hs, g->gvs = vs;
+  g->committed = false;
+  return LK_ERROR_NONE;
+}
+int lk_group_set_sector_annular(lk_group *g, int sector, float r, float dr, float a, float da, float cx, float cy,
+                                int as) {
+  SectorSpec *s = spec_slot(g, sector);
+  if (!s)
+    return LK_ERROR_BAD_DOMAIN;
+  *s = SectorSpec();
+  s->kind = 2, s->r = r, s->dr = dr, s->a = a, s->da = da, s->cx = cx, s->cy = cy, s->as = as;
+  return LK_ERROR_NONE;
+}
+int lk_group_set_sector_points(lk_group *g, int sector, const float *xy, int n, int use_center, float cx, float cy) {
+  SectorSpec *s = spec_slot(g, sector);
+  if (!s || !xy || n < 1)
+    return g ? g->fail(LK_ERROR_BAD_DOMAIN, "lk_group_set_sector_points: empty list") : LK_ERROR_BAD_DOMAIN;
+  *s = SectorSpec();
+  s->kind = 3, s->xy.assign(xy, xy + 2 * (size_t)n), s->use_center = use_center, s->cx = cx, s->cy = cy;
+  return LK_ERROR_NONE;
+}
+int lk_group_sector_count(const lk_group *g) {
+  return g ? (g->committed ? g->S : (g->grid ? g->ghs * g->gvs : (int)g->secs.size())) : 0;
+}
+
+int lk_group_commit_sectors(lk_group *g) {
+  if (!g)
+    return LK_ERROR_BAD_DOMAIN;
+  const int n = (int)g->m.size();
+  const int S = g->grid ? g->ghs * g->gvs : (int)g->secs.size();
+  if (S < n)
+    return g->fail(LK_ERROR_BAD_DOMAIN, "lk_group_commit_sectors: fewer sectors than devices");
+  if (!g->grid)
+    for (int s = 0; s < S; ++s)
+      if (g->secs[(size_t)s].kind == 0)
+        return g->fail(LK_ERROR_BAD_DOMAIN, "lk_group_commit_sectors: sector " + std::to_string(s) + " was never set");
+  const int cap = (S + n - 1) / n; // equal all-gather blocks: the shards differ by at most one sector
+  int rc = g->run([=](Member &me) -> int {
+    shard(S, me.rank, n, me.first, me.count);
+    if (g->grid) {
+      GLK(lk_set_rect_grid(me.e, g->gx0, g->gy0, g->gx1, g->gy1, g->ghs, g->gvs, me.first, me.count));
+    } else {
+      GLK(lk_clear_sectors(me.e));
+      for (int k = 0; k < me.count; ++k) {
+        const SectorSpec &s = g->secs[(size_t)(me.first + k)];
+        if (s.kind == 1)
+          GLK(lk_set_sector_rect(me.e, k, s.x0, s.y0, s.x1, s.y1));
+        else if (s.kind == 2)
+          GLK(lk_set_sector_annular(me.e, k, s.r, s.dr, s.a, s.da, s.cx, s.cy, s.as));
+        else
+          GLK(lk_set_sector_points(me.e, k, s.xy.data(), (int)(s.xy.size() / 2), s.use_center, s.cx, s.cy));
+      }
+    }
+    GLK(lk_commit_sectors(me.e));
+    if (me.cap < (size_t)cap) {
+      GLK(lk_synchronize(me.e));
+      for (void *p : {(void *)me.d_guess, (void *)me.d_rec, (void *)me.d_all})
+        if (p)
+          GHIP(hipFree(p));
+      me.d_guess = nullptr, me.d_rec = nullptr, me.d_all = nullptr, me.cap = 0;
+      GHIP(hipMalloc((void **)&me.d_guess, 6 * (size_t)cap * sizeof(float)));
+      GHIP(hipMalloc((void **)&me.d_rec, (size_t)cap * sizeof(lk_result)));
+      GHIP(hipMalloc((void **)&me.d_all, (size_t)n * (size_t)cap * sizeof(lk_result)));
+      me.cap = (size_t)cap;
+    }
+    GHIP(hipMemsetAsync(me.d_rec, 0, me.cap * sizeof(lk_result), me.st)); // (the padding record stays zero)
+    GHIP(hipMemsetAsync(me.d_guess, 0, 6 * me.cap * sizeof(float), me.st));
+    return LK_ERROR_NONE;
+  });
+  if (rc)
+    return rc;
+  g->S = S;
+  g->cap = cap;
+  g->committed = true;
+  return LK_ERROR_NONE;
+}
+
+// ---- the solve ----------------------------------------------------------------------------------
+int lk_group_correlate_all(lk_group *g, const float *guesses, lk_result *out) {
+  if (!g)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!g->committed)
+    return g->fail(LK_ERROR_BAD_DOMAIN, "lk_group_correlate_all: sectors are not committed");
+  const int n = (int)g->m.size();
+  const size_t block = (size_t)g->cap * sizeof(lk_result);
+  return g->run([=](Member &me) -> int {
+    if (guesses)
+      GHIP(hipMemcpyAsync(me.d_guess, guesses + 6 * (size_t)me.first, 6 * (size_t)me.count * sizeof(float),
+                          hipMemcpyHostToDevice, me.st));
+    GLK(lk_correlate_all_device(me.e, guesses ? me.d_guess : nullptr, me.d_rec));
+    if (!g->loopback) {
+      GNCCL(ncclAllGather(me.d_rec, me.d_all, block, ncclUint8, me.comm, me.st));
+    } else {
+      GHIP(hipStreamSynchronize(me.st));
+      g->barrier(); // every block is final
+      for (int q = 0; q < n; ++q)
+        GHIP(hipMemcpyAsync((char *)g->m[(size_t)q].d_all + (size_t)me.rank * block, me.d_rec, block,
+                            hipMemcpyDeviceToDevice, me.st));
+      GHIP(hipStreamSynchronize(me.st));
+      g->barrier(); // everybody's d_all is complete
+    }
+    if (out && me.rank == 0) { // global sector order: block r starts at rank r's first sector
+      for (int q = 0; q < n; ++q) {
+        int first, count;
+        shard(g->S, q, n, first, count);
+        GHIP(hipMemcpyAsync(out + first, (const char *)me.d_all + (size_t)q * block, (size_t)count * sizeof(lk_result),
+                            hipMemcpyDeviceToHost, me.st));
+      }
+      GHIP(hipStreamSynchronize(me.st));
+    }
+    return LK_ERROR_NONE;
+  });
+}
+
+int lk_group_adjust_initial_guess(lk_group *g, int frame, int constant_velocity, const float *global_guess,
+                                  float global_cx, float global_cy) {
+  if (!g)
+    return LK_ERROR_BAD_DOMAIN;
+  float gg[6] = {0, 0, 0, 0, 0, 0};
+  if (global_guess)
+    std::memcpy(gg, global_guess, sizeof gg);
+  const std::vector<float> ggv(gg, gg + 6);
+  return g->run([=](Member &me) -> int {
+    GLK(lk_adjust_initial_guess(me.e, frame, constant_velocity, ggv.data(), global_cx, global_cy));
+    return LK_ERROR_NONE;
+  });
+}
+
+int lk_group_records_device(lk_group *g, int rank, const void **d_records) {
+  if (!g || !d_records || rank < 0 || rank >= (int)g->m.size() || !g->committed)
+    return LK_ERROR_BAD_DOMAIN;
+  *d_records = g->m[(size_t)rank].d_all;
+  return LK_ERROR_NONE;
+}
+int lk_group_block_records(const lk_group *g) { return g ? g->cap : 0; }
+
+int lk_group_synchronize(lk_group *g) {
+  if (!g)
+    return LK_ERROR_BAD_DOMAIN;
+  return g->run([=](Member &me) -> int {
+    GLK(lk_synchronize(me.e));
+    GHIP(hipStreamSynchronize(me.st));
+    return LK_ERROR_NONE;
+  });
+}
+
+int lk_group_get_stats(lk_group *g, lk_stats *out) {
+  if (!g || !out)
+    return LK_ERROR_BAD_DOMAIN;
+  std::vector<lk_stats> st(g->m.size());
+  int rc = g->run([&](Member &me) -> int {
+    GLK(lk_get_stats(me.e, &st[(size_t)me.rank]));
+    return LK_ERROR_NONE;
+  });
+  if (rc)
+    return rc;
+  lk_stats s{};
+  for (const lk_stats &q : st) {
+    s.sectors += q.sectors;
+    s.evaluations += q.evaluations;
+    s.sample_evaluations += q.sample_evaluations;
+    s.point_iterations += q.point_iterations;
+    s.algorithmic_bytes += q.algorithmic_bytes;
+    s.ill_conditioned_solves += q.ill_conditioned_solves;
+    s.solve_ms = std::max(s.solve_ms, q.solve_ms);
+    s.pyramid_ms = std::max(s.pyramid_ms, q.pyramid_ms);
+  }
+  *out = s;
+  return LK_ERROR_NONE;
+}
+
+} // extern "C"

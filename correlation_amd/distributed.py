@@ -18,6 +18,11 @@ from .workload import shard_range
 
 
 class ShardedCorrelator:
+    """device = a torch device: frames and records stay in HBM.  torch, RCCL and the engine then share
+    ONE HIP stream (a torch.cuda.Stream handed to lk_set_stream): RCCL orders its kernels against
+    torch's current stream only, so the broadcast, the engine's upload + pyramid launch, the solve and
+    the all-gather are ordered by that stream alone - no event hand-off between two streams to forget."""
+
     def __init__(self, engine, dist=None, device=None):
         self.e = engine
         self.dist = dist
@@ -27,6 +32,13 @@ class ShardedCorrelator:
         self.first = 0
         self.count = 0
         self.total = 0
+        self.stream = None
+        self._frames = {}      # slot -> device tensor the engine's (asynchronous) pyramid launch reads
+        self._rec = None
+        if device is not None and hasattr(engine, "set_stream"):
+            import torch
+            self.stream = torch.cuda.Stream(device)
+            engine.set_stream(self.stream.cuda_stream)
 
     def set_rect_grid(self, x_begin, y_begin, x_end, y_end, hs, vs):
         """Every rank registers only its own block of the hs*vs sector grid."""
@@ -39,38 +51,71 @@ class ShardedCorrelator:
         """pixels: uint8 (H, W) array on rank 0 (ignored elsewhere, only its shape is used)."""
         import torch
         t = torch.from_numpy(np.ascontiguousarray(pixels, np.uint8))
-        if self.device is not None:
-            t = t.to(self.device)
-        if self.dist is not None and self.world > 1:
-            self.dist.broadcast(t, src=0)
-        if self.device is not None and hasattr(self.e, "set_image_device"):
-            self.e.set_image_device(slot, t.data_ptr(), t.shape[0], t.shape[1])
-            self._keep = t  # the engine copies during the call; keep alive until then
-        else:
-            self.e.set_image(slot, t.cpu().numpy())
+        if self.device is None or self.stream is None:
+            if self.dist is not None and self.world > 1:
+                self.dist.broadcast(t, src=0)
+            self.e.set_image(slot, t.numpy())
+            return
+        with torch.cuda.stream(self.stream):
+            d = t.to(self.device, non_blocking=False)
+            if self.dist is not None and self.world > 1:
+                self.dist.broadcast(d, src=0)                   # RCCL, on self.stream
+            self.e.set_image_device(slot, d.data_ptr(), d.shape[0], d.shape[1])   # same stream: after the broadcast
+            d.record_stream(self.stream)
+        # the previous tensor of this slot may still be read by a queued pyramid launch: it is
+        # released only after that launch, because everything runs on self.stream in order and the
+        # caching allocator hands memory back to the stream the tensor was recorded on
+        self._frames[slot] = d
 
     def correlate_all(self, guesses=None):
         """Returns the records of ALL sectors (same on every rank), in sector order."""
         import torch
-        local = self.e.correlate_all(guesses)
-        if self.dist is None or self.world == 1:
-            return local
-        rec = local.dtype
-        # blocks differ by at most one sector: pad to the largest, gather, trim
-        cap = (self.total + self.world - 1) // self.world
-        buf = np.zeros((cap, rec.itemsize), np.uint8)
-        buf[:len(local)] = local.view(np.uint8).reshape(len(local), rec.itemsize)
-        t = torch.from_numpy(buf)
-        if self.device is not None:
-            t = t.to(self.device)
-        out = torch.empty((self.world * cap, rec.itemsize), dtype=torch.uint8, device=t.device)
-        self.dist.all_gather_into_tensor(out, t)
-        out = out.cpu().numpy().reshape(self.world, cap, rec.itemsize)
+        rec = np.dtype(self._record_dtype())
+        cap = (self.total + self.world - 1) // self.world if self.total else 0
+        if self.device is not None and self.stream is not None and hasattr(self.e, "correlate_all_device"):
+            # device path: guesses up once, records gathered in HBM, one copy down
+            with torch.cuda.stream(self.stream):
+                n = self.count or self.e.n_sectors
+                cap = max(cap, n)
+                g = torch.zeros((n, 6), dtype=torch.float32, device=self.device)
+                if guesses is not None:
+                    ga = np.asarray(guesses, np.float32)
+                    gh = np.zeros((n, 6), np.float32)
+                    if ga.ndim == 1:
+                        gh[:, :ga.shape[0]] = ga
+                    else:
+                        gh[:, :ga.shape[1]] = ga
+                    g.copy_(torch.from_numpy(gh))
+                if self._rec is None or self._rec.shape[0] != cap:
+                    self._rec = torch.zeros((cap, rec.itemsize), dtype=torch.uint8, device=self.device)
+                self.e.correlate_all_device(g.data_ptr(), self._rec.data_ptr())
+                if self.dist is None or self.world == 1:
+                    out = self._rec[:n].cpu().numpy()
+                    return out.reshape(-1).view(rec)
+                gathered = torch.empty((self.world * cap, rec.itemsize), dtype=torch.uint8, device=self.device)
+                self.dist.all_gather_into_tensor(gathered, self._rec)      # RCCL, same stream: after the solve
+                out = gathered.cpu().numpy().reshape(self.world, cap, rec.itemsize)
+        else:
+            local = self.e.correlate_all(guesses)
+            if self.dist is None or self.world == 1:
+                return local
+            # blocks differ by at most one sector: pad to the largest, gather, trim
+            buf = np.zeros((cap, rec.itemsize), np.uint8)
+            buf[:len(local)] = local.view(np.uint8).reshape(len(local), rec.itemsize)
+            t = torch.from_numpy(buf)
+            gathered = torch.empty((self.world * cap, rec.itemsize), dtype=torch.uint8)
+            self.dist.all_gather_into_tensor(gathered, t)
+            out = gathered.numpy().reshape(self.world, cap, rec.itemsize)
         parts = []
         for r in range(self.world):
             _, cnt = shard_range(self.total, r, self.world)
             parts.append(out[r, :cnt].reshape(-1).view(rec))
         return np.concatenate(parts)
+
+    @staticmethod
+    def _record_dtype():
+        from ._ffi import RESULT_DTYPE
+        return RESULT_DTYPE
 
 
 class ShardedSequence:

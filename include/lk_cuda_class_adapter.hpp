@@ -5,7 +5,8 @@
 //   reference call site (manager_class.cpp / mainapp.cpp)        forwards to
 //   ---------------------------------------------------------    ---------------------------
 //   cuda_manager->initialize()                mainapp.cpp:824     lk_device_count
-//   set_deviceCount / set_max_iters / set_precision /
+//   set_deviceCount(n)                           :1677            n > 1: lk_group (one engine per device)
+//   set_max_iters / set_precision /
 //   set_fitting_model / set_interpolation_model  :1677-1685       stored, applied at (re)create
 //   resetImagePyramids(und,def,nxt,color,start,step,stop) :915    lk_create + lk_set_image x3
 //   resetNextPyramid(path)              manager_class.cpp:257     lk_set_image(LK_IMG_NXT)
@@ -42,6 +43,7 @@
 #include "domains.hpp" // reference: CorrelationResult, frame_results, v_points
 #include "enums.hpp"   // reference: errorEnum, fittingModelEnum, ...
 #include "lk_engine.h"
+#include "lk_group.h"
 
 #ifdef LK_ADAPTER_WITH_OPENCV
 #include <opencv2/core/core.hpp>
@@ -50,6 +52,7 @@
 
 class HipCudaClass {
   lk_engine *engine_ = nullptr;
+  lk_group *group_ = nullptr; // set_deviceCount(n > 1): one engine per device, sectors sharded (lk_group.h)
   lk_config cfg_{LK_IM_BICUBIC, LK_FM_UVUXUYVXVY, 0.001f, 50, 0, 1, 2, 0};
   int deviceCount_ = 1;
   bool sectors_dirty_ = false;
@@ -59,20 +62,42 @@ class HipCudaClass {
   static_assert(sizeof(CorrelationResult) == sizeof(lk_result), "lk_result must mirror CorrelationResult");
 
   bool ensure_engine() {
-    if (engine_)
+    if (engine_ || group_)
       return true;
+    if (deviceCount_ > 1)
+      return lk_group_create(&cfg_, deviceCount_, nullptr, &group_) == LK_ERROR_NONE;
     return lk_create(&cfg_, &engine_) == LK_ERROR_NONE;
   }
   void recreate() {
     if (engine_)
       lk_destroy(engine_);
+    if (group_)
+      lk_group_destroy(group_);
     engine_ = nullptr;
+    group_ = nullptr;
   }
   bool commit() {
     if (!sectors_dirty_)
       return true;
     sectors_dirty_ = false;
-    return lk_commit_sectors(engine_) == LK_ERROR_NONE;
+    return (group_ ? lk_group_commit_sectors(group_) : lk_commit_sectors(engine_)) == LK_ERROR_NONE;
+  }
+  // group mode: the engine that owns a global sector index and the sector's index there
+  lk_engine *owner(int iSector, int *local) {
+    if (!group_) {
+      *local = iSector;
+      return engine_;
+    }
+    for (int r = 0; r < lk_group_size(group_); ++r) {
+      int first = 0, count = 0;
+      lk_engine *e = nullptr;
+      if (lk_group_shard(group_, r, &first, &count) == LK_ERROR_NONE && iSector >= first && iSector < first + count &&
+          lk_group_engine(group_, r, &e) == LK_ERROR_NONE) {
+        *local = iSector - first;
+        return e;
+      }
+    }
+    return nullptr;
   }
 
 public:
@@ -83,7 +108,17 @@ public:
 
   int initialize() { return lk_device_count(); } // cuda_class.cu:39-75
 
-  void set_deviceCount(int n) { deviceCount_ = n; } // README.md:33: always 1 per engine
+  // cuda_class.cu:77-83.  The reference keeps this at 1 (README.md:33, `iGPU = 0` cuda_class.cu:333); here
+  // n > 1 shards the sectors over n devices (include/lk_group.h): register every sector, then solve the
+  // frame with correlateAll().  correlate(iSector) works too (on the owning device) once all sectors are
+  // registered; interleaving registration and per-sector solves re-deals the shards at every commit.
+  void set_deviceCount(int n) {
+    n = n < 1 ? 1 : n;
+    if (n != deviceCount_) {
+      deviceCount_ = n;
+      recreate();
+    }
+  }
   void set_max_iters(int n) {
     if (cfg_.max_iters != n) {
       cfg_.max_iters = n;
@@ -121,15 +156,15 @@ public:
     }
     if (!ensure_engine())
       return error_cuda;
-    int rc = lk_set_image(engine_, LK_IMG_UND, und, rows, cols, step);
+    int rc = set_image(LK_IMG_UND, und, rows, cols, step);
     if (!rc)
-      rc = lk_set_image(engine_, LK_IMG_DEF, def, rows, cols, step);
+      rc = set_image(LK_IMG_DEF, def, rows, cols, step);
     if (!rc && nxt)
-      rc = lk_set_image(engine_, LK_IMG_NXT, nxt, rows, cols, step);
+      rc = set_image(LK_IMG_NXT, nxt, rows, cols, step);
     return (errorEnum)rc;
   }
   errorEnum resetNextPyramid(const uint8_t *nxt, int rows, int cols, int step) {
-    return ensure_engine() ? (errorEnum)lk_set_image(engine_, LK_IMG_NXT, nxt, rows, cols, step) : error_cuda;
+    return ensure_engine() ? (errorEnum)set_image(LK_IMG_NXT, nxt, rows, cols, step) : error_cuda;
   }
 #ifdef LK_ADAPTER_WITH_OPENCV
   void resetImagePyramids(const std::string undPath, const std::string defPath, const std::string nxtPath,
@@ -145,11 +180,15 @@ public:
   }
 #endif
   void makeUndPyramidFromDef() {
-    if (engine_)
+    if (group_)
+      lk_group_rotate_und_from_def(group_);
+    else if (engine_)
       lk_rotate_und_from_def(engine_);
   }
   void makeDefPyramidFromNxt() {
-    if (engine_)
+    if (group_)
+      lk_group_rotate_def_from_nxt(group_);
+    else if (engine_)
       lk_rotate_def_from_nxt(engine_);
   }
 
@@ -157,17 +196,21 @@ public:
     if (!ensure_engine())
       return error_cuda;
     sectors_dirty_ = true;
-    return (errorEnum)lk_set_sector_rect(engine_, iSector, x0, y0, x1, y1);
+    return (errorEnum)(group_ ? lk_group_set_sector_rect(group_, iSector, x0, y0, x1, y1)
+                              : lk_set_sector_rect(engine_, iSector, x0, y0, x1, y1));
   }
   errorEnum resetPolygon(int iSector, float r, float dr, float a, float da, float cx, float cy, int as) {
     if (!ensure_engine())
       return error_cuda;
     sectors_dirty_ = true;
-    return (errorEnum)lk_set_sector_annular(engine_, iSector, r, dr, a, da, cx, cy, as);
+    return (errorEnum)(group_ ? lk_group_set_sector_annular(group_, iSector, r, dr, a, da, cx, cy, as)
+                              : lk_set_sector_annular(engine_, iSector, r, dr, a, da, cx, cy, as));
   }
   errorEnum resetPolygon(v_points blobContour) { // the blob domain is always sector 0
     if (!ensure_engine())
       return error_cuda;
+    if (group_)
+      return error_bad_domain; // one sector: nothing to shard - use set_deviceCount(1)
     std::vector<float> c;
     c.reserve(2 * blobContour.size());
     for (const auto &pt : blobContour) {
@@ -182,13 +225,17 @@ public:
   // call rebuilds the engine's lists before the next solve; whole frames go through
   // lk_sequence_frame / lk_translate_sectors / lk_rewarp_sectors (include/lk_tracker.h).
   void updatePolygon(int iSector, deformationDescriptionEnum deformationDescription) {
+    int local = 0;
     if (ensure_engine() && commit())
-      lk_update_sector(engine_, iSector, (int)deformationDescription);
+      if (lk_engine *e = owner(iSector, &local))
+        lk_update_sector(e, local, (int)deformationDescription);
   }
 
   CorrelationResult *correlate(int iSector, float *initial_guess_, frame_results & /*results*/) {
     lk_result r{};
-    int rc = ensure_engine() && commit() ? lk_correlate(engine_, iSector, initial_guess_, &r) : LK_ERROR_DEVICE;
+    int local = 0;
+    lk_engine *e = ensure_engine() && commit() ? owner(iSector, &local) : nullptr;
+    int rc = e ? lk_correlate(e, local, initial_guess_, &r) : LK_ERROR_DEVICE;
     if (rc)
       r.errorCode = rc;
     for (int i = 0; i < 6; ++i)
@@ -206,9 +253,10 @@ public:
   const CorrelationResult *correlateAll(const float *guesses /*[S][6]*/, int *count) {
     if (!ensure_engine() || !commit())
       return nullptr;
-    int S = lk_sector_count(engine_);
+    int S = group_ ? lk_group_sector_count(group_) : lk_sector_count(engine_);
     batch_.resize((size_t)S);
-    if (lk_correlate_all(engine_, guesses, batch_.data()) != LK_ERROR_NONE)
+    if ((group_ ? lk_group_correlate_all(group_, guesses, batch_.data()) : lk_correlate_all(engine_, guesses, batch_.data())) !=
+        LK_ERROR_NONE)
       return nullptr;
     if (count)
       *count = S;
@@ -217,11 +265,12 @@ public:
 
   v_points getUndXY0ToCPU(int iSector) {
     v_points out;
-    int n = 0;
-    if (!engine_ || lk_get_und_xy(engine_, iSector, nullptr, 0, &n) != LK_ERROR_NONE)
+    int n = 0, local = 0;
+    lk_engine *e = (engine_ || (group_ && commit())) ? owner(iSector, &local) : nullptr;
+    if (!e || lk_get_und_xy(e, local, nullptr, 0, &n) != LK_ERROR_NONE)
       return out;
     std::vector<float> xy(2 * (size_t)n);
-    lk_get_und_xy(engine_, iSector, xy.data(), n, &n);
+    lk_get_und_xy(e, local, xy.data(), n, &n);
     out.resize((size_t)n);
     for (int i = 0; i < n; ++i)
       out[(size_t)i] = std::make_pair(xy[2 * (size_t)i], xy[2 * (size_t)i + 1]);
@@ -230,11 +279,12 @@ public:
   // the reference warps with the sector's last result; pass it explicitly
   v_points getDefXY0ToCPU(int iSector, const float *parameters) {
     v_points out;
-    int n = 0;
-    if (!engine_ || !commit() || lk_get_def_xy(engine_, iSector, parameters, nullptr, 0, &n) != LK_ERROR_NONE)
+    int n = 0, local = 0;
+    lk_engine *e = (engine_ || group_) && commit() ? owner(iSector, &local) : nullptr;
+    if (!e || lk_get_def_xy(e, local, parameters, nullptr, 0, &n) != LK_ERROR_NONE)
       return out;
     std::vector<float> xy(2 * (size_t)n);
-    lk_get_def_xy(engine_, iSector, parameters, xy.data(), n, &n);
+    lk_get_def_xy(e, local, parameters, xy.data(), n, &n);
     out.resize((size_t)n);
     for (int i = 0; i < n; ++i)
       out[(size_t)i] = std::make_pair(xy[2 * (size_t)i], xy[2 * (size_t)i + 1]);
@@ -243,4 +293,10 @@ public:
   v_points getDefXY0ToCPU(int iSector) { return getDefXY0ToCPU(iSector, last_.resultingParameters); }
 
   lk_engine *handle() { return engine_; }
+  lk_group *group_handle() { return group_; }
+
+private:
+  int set_image(int slot, const uint8_t *px, int rows, int cols, int step) {
+    return group_ ? lk_group_set_image(group_, slot, px, rows, cols, step) : lk_set_image(engine_, slot, px, rows, cols, step);
+  }
 };

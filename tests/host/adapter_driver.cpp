@@ -31,10 +31,11 @@ static std::vector<uint8_t> slurp(const char *path, size_t n) {
 }
 
 int main(int argc, char **argv) {
-  if (argc != 11) {
-    std::fprintf(stderr, "usage: adapter_driver und.raw def.raw nxt.raw rows cols x_begin x_end hs vs out.bin\n");
+  if (argc != 11 && argc != 12) {
+    std::fprintf(stderr, "usage: adapter_driver und.raw def.raw nxt.raw rows cols x_begin x_end hs vs out.bin [devices]\n");
     return 2;
   }
+  const int devices = argc == 12 ? std::atoi(argv[11]) : 1;
   const int rows = std::atoi(argv[4]), cols = std::atoi(argv[5]);
   const float fx0 = (float)std::atof(argv[6]), fx1 = (float)std::atof(argv[7]);
   const int hs = std::atoi(argv[8]), vs = std::atoi(argv[9]);
@@ -43,7 +44,7 @@ int main(int argc, char **argv) {
   HipCudaClass c;
   if (c.initialize() < 1)
     return 4;
-  c.set_deviceCount(1);
+  c.set_deviceCount(devices); // > 1: one engine per device behind the same calls (include/lk_group.h)
   c.set_max_iters(50);
   c.set_precision(0.001f);
   c.set_fitting_model(fm_UVUxUyVxVy);
@@ -51,7 +52,8 @@ int main(int argc, char **argv) {
   if (c.resetImagePyramids(und.data(), def.data(), nxt.data(), rows, cols, cols, color_monochrome, 0, 1, 2) != error_none)
     return 5;
 #ifndef ADAPTER_DRIVER_MOCK
-  lk_set_batch_invariant(c.handle(), 1); // a sector's record then does not depend on what else is in the launch
+  if (c.handle())
+    lk_set_batch_invariant(c.handle(), 1); // a sector's record then does not depend on what else is in the launch
 #endif
   // sector geometry of the rectangular domain, manager_class.cpp:283-310
   const int x0 = (int)fx0, x1 = (int)fx1;
@@ -68,12 +70,33 @@ int main(int argc, char **argv) {
       const int cy = (int)(0.5f + fx0 + fydim + (2.f * fydim + 1.f) * (float)j);
       if (c.resetPolygon(iSector, cx - xdim, cy - ydim, cx + xdim, cy + ydim) != error_none)
         return 6;
-      out[(size_t)iSector] = *c.correlate(iSector, &guess[(size_t)6 * iSector], fr);
+      if (devices == 1)
+        out[(size_t)iSector] = *c.correlate(iSector, &guess[(size_t)6 * iSector], fr);
     }
+  if (devices > 1) { // several devices: every sector registered first, then the frame in one sharded solve
+    int n = 0;
+    const CorrelationResult *all = c.correlateAll(guess.data(), &n);
+    if (!all || n != S)
+      return 8;
+    for (int s = 0; s < S; ++s) {
+      out[(size_t)s] = all[s];
+      for (int i = 0; i < 6; ++i)
+        guess[(size_t)6 * s + i] = all[s].resultingParameters[i];
+    }
+  }
   c.makeDefPyramidFromNxt();
   for (int iSector = 0; iSector < S; ++iSector) {
     c.updatePolygon(iSector, def_Lagrangian);
-    out[(size_t)S + iSector] = *c.correlate(iSector, &guess[(size_t)6 * iSector], fr); // guess = the previous result
+    if (devices == 1)
+      out[(size_t)S + iSector] = *c.correlate(iSector, &guess[(size_t)6 * iSector], fr); // guess = the previous result
+  }
+  if (devices > 1) {
+    int n = 0;
+    const CorrelationResult *all = c.correlateAll(guess.data(), &n);
+    if (!all || n != S)
+      return 9;
+    for (int s = 0; s < S; ++s)
+      out[(size_t)S + s] = all[s];
   }
   FILE *f = std::fopen(argv[10], "wb");
   if (!f || std::fwrite(out.data(), sizeof(CorrelationResult), out.size(), f) != out.size())

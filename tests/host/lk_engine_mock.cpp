@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "lk_engine.h"
+#include "lk_group.h"
 
 namespace {
 struct Sector {
@@ -313,5 +314,112 @@ int lk_get_def_xy(lk_engine *e, int s, const float *p, float *xy, int cap, int *
     for (int i = 0; i < *count && i < cap; ++i)
       xy[2 * i] += p[0], xy[2 * i + 1] += p[1];
   return rc;
+}
+
+// ---- include/lk_group.h over n mock engines: same partition rule, sectors re-dealt at commit --------
+struct lk_group_mock_spec {
+  int kind = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0, as = 1;
+  float r = 0, dr = 0, a = 0, da = 0, cx = 0, cy = 0;
+};
+}
+struct lk_group {
+  std::vector<lk_engine *> e;
+  std::vector<lk_group_mock_spec> secs;
+  bool committed = false;
+};
+extern "C" {
+int lk_group_shard_range(int S, int rank, int n, int *first, int *count) {
+  *first = (int)((long long)S * rank / n);
+  *count = (int)((long long)S * (rank + 1) / n) - *first;
+  return 0;
+}
+int lk_group_create(const lk_config *cfg, int n, const int *, lk_group **out) {
+  lk_group *g = new lk_group();
+  for (int r = 0; r < n; ++r) {
+    lk_engine *e = nullptr;
+    lk_create(cfg, &e);
+    g->e.push_back(e);
+  }
+  *out = g;
+  J("group_create n=%d", n);
+  return 0;
+}
+void lk_group_destroy(lk_group *g) {
+  for (lk_engine *e : g->e)
+    lk_destroy(e);
+  delete g;
+}
+int lk_group_size(const lk_group *g) { return (int)g->e.size(); }
+int lk_group_engine(lk_group *g, int rank, lk_engine **e) {
+  *e = g->e[(size_t)rank];
+  return 0;
+}
+int lk_group_shard(const lk_group *g, int rank, int *first, int *count) {
+  return lk_group_shard_range((int)g->secs.size(), rank, (int)g->e.size(), first, count);
+}
+int lk_group_set_image(lk_group *g, int slot, const uint8_t *px, int rows, int cols, int step) {
+  for (lk_engine *e : g->e)
+    if (int rc = lk_set_image(e, slot, px, rows, cols, step))
+      return rc;
+  return 0;
+}
+int lk_group_rotate_und_from_def(lk_group *g) {
+  for (lk_engine *e : g->e)
+    lk_rotate_und_from_def(e);
+  return 0;
+}
+int lk_group_rotate_def_from_nxt(lk_group *g) {
+  for (lk_engine *e : g->e)
+    if (int rc = lk_rotate_def_from_nxt(e))
+      return rc;
+  return 0;
+}
+int lk_group_set_sector_rect(lk_group *g, int s, int x0, int y0, int x1, int y1) {
+  if ((size_t)s >= g->secs.size())
+    g->secs.resize((size_t)s + 1);
+  g->secs[(size_t)s] = lk_group_mock_spec{1, x0, y0, x1, y1, 1, 0, 0, 0, 0, 0, 0};
+  g->committed = false;
+  return 0;
+}
+int lk_group_set_sector_annular(lk_group *g, int s, float r, float dr, float a, float da, float cx, float cy, int as) {
+  if ((size_t)s >= g->secs.size())
+    g->secs.resize((size_t)s + 1);
+  g->secs[(size_t)s] = lk_group_mock_spec{2, 0, 0, 0, 0, as, r, dr, a, da, cx, cy};
+  g->committed = false;
+  return 0;
+}
+int lk_group_commit_sectors(lk_group *g) {
+  const int n = (int)g->e.size(), S = (int)g->secs.size();
+  for (int r = 0; r < n; ++r) {
+    int first, count;
+    lk_group_shard_range(S, r, n, &first, &count);
+    lk_clear_sectors(g->e[(size_t)r]);
+    for (int k = 0; k < count; ++k) {
+      const lk_group_mock_spec &q = g->secs[(size_t)(first + k)];
+      if (q.kind == 1)
+        lk_set_sector_rect(g->e[(size_t)r], k, q.x0, q.y0, q.x1, q.y1);
+      else
+        lk_set_sector_annular(g->e[(size_t)r], k, q.r, q.dr, q.a, q.da, q.cx, q.cy, q.as);
+    }
+    if (int rc = lk_commit_sectors(g->e[(size_t)r]))
+      return rc;
+  }
+  g->committed = true;
+  J("group_commit S=%d over %d", S, n);
+  return 0;
+}
+int lk_group_sector_count(const lk_group *g) { return (int)g->secs.size(); }
+int lk_group_correlate_all(lk_group *g, const float *guesses, lk_result *out) {
+  if (!g->committed)
+    return LK_ERROR_BAD_DOMAIN;
+  const int n = (int)g->e.size(), S = (int)g->secs.size();
+  for (int r = 0; r < n; ++r) {
+    int first, count;
+    lk_group_shard_range(S, r, n, &first, &count);
+    if (int rc = lk_correlate_all(g->e[(size_t)r], guesses ? guesses + 6 * (size_t)first : nullptr, out + first))
+      return rc;
+  }
+  J("group_correlate_all S=%d", S);
+  return 0;
 }
 }

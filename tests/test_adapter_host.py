@@ -70,6 +70,31 @@ def test_adapter_against_the_mock_in_manager_order(tmp_path):
     assert np.allclose(rec["p"][1][:, 0], rec["p"][0][:, 0] + 0.0025 * (rec["und_cx"][1] - 64.0))
 
 
+def test_adapter_with_several_devices_against_the_mock(tmp_path):
+    """set_deviceCount(3): the same HipCudaClass calls go to lk_group (one engine per device, sectors in
+    contiguous blocks); the records must be the one-device run's, sector for sector."""
+    exe = tmp_path / "adapter_mock"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-Wall", "-Wextra", "-Werror", "-DADAPTER_DRIVER_MOCK",
+                        "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                        "-I" + os.path.join(ROOT, "include"), "-I" + ref_include(),
+                        os.path.join(HOST, "adapter_driver.cpp"), os.path.join(HOST, "lk_engine_mock.cpp"), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rng = np.random.default_rng(1)
+    frames = write_frames(tmp_path, [rng.integers(0, 256, (160, 160), dtype=np.uint8) for _ in range(3)])
+    recs = {}
+    for devices in (1, 3):
+        out = tmp_path / f"out{devices}.bin"
+        r = subprocess.run([str(exe)] + frames + ["160", "160", "8", "151", "5", "4", str(out), str(devices)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        recs[devices] = np.fromfile(out, ca.RESULT_DTYPE)
+        if devices == 3:
+            assert "group_create n=3" in r.stdout and "group_commit S=20 over 3" in r.stdout
+            assert r.stdout.count("group_correlate_all S=20") == 2
+    assert recs[1].tobytes() == recs[3].tobytes()
+
+
 @pytest.mark.gpu
 def test_adapter_per_sector_loop_equals_the_batched_path(tmp_path):
     """The literal drop-in: HipCudaClass driven like managerClass drives CudaClass, on the engine."""

@@ -1,5 +1,5 @@
 """CPU-side checks of the product boundary: the C-ABI library builds for gfx950, loads,
-exports every symbol include/lk_engine.h and include/lk_tracker.h declare, and refuses to run without a HIP
+exports every symbol include/lk_engine.h, lk_tracker.h and lk_group.h declare, and refuses to run without a HIP
 device (no CPU fallback)."""
 import ctypes as C
 import os
@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_functions():
     names = set()
-    for header in ("lk_engine.h", "lk_tracker.h"):
+    for header in ("lk_engine.h", "lk_tracker.h", "lk_group.h"):
         hdr = open(os.path.join(ROOT, "include", header)).read()
         hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
         hdr = re.sub(r"typedef[^;]*\(\*lk_[a-z_0-9]+\)[^;]*;", "", hdr)      # function-pointer typedefs

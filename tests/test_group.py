@@ -1,0 +1,190 @@
+"""include/lk_group.h: the single-process multi-GPU engine.
+CPU: the partition rule.  GPU (one MI355X): a 1-device group - RCCL communicator, broadcast and
+all-gather included - must equal the plain engine bit for bit; groups of several ranks on the SAME
+device (the rehearsal transport: copies instead of RCCL, every other line of code the same) must
+equal it too, for grids, mixed sectors, uneven shards and a tracked constant-velocity sequence."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import correlation_amd as ca
+from correlation_amd import _ffi
+from correlation_amd.workload import shard_range
+
+
+def test_partition_rule(engine_lib):
+    f, c = C.c_int(), C.c_int()
+    for S in (1, 2, 7, 8, 9, 63, 64, 65, 10000, 50176, 199809):
+        for n in (1, 2, 3, 4, 5, 8):
+            if S < n:
+                continue
+            nxt, sizes = 0, []
+            for r in range(n):
+                assert engine_lib.lk_group_shard_range(S, r, n, C.byref(f), C.byref(c)) == 0
+                assert (f.value, c.value) == shard_range(S, r, n)      # the Python harness uses the same rule
+                assert f.value == nxt                                   # contiguous, in rank order
+                nxt += c.value
+                sizes.append(c.value)
+            assert nxt == S and max(sizes) - min(sizes) <= 1 and max(sizes) <= (S + n - 1) // n
+    assert engine_lib.lk_group_shard_range(10, 3, 3, C.byref(f), C.byref(c)) == ca.ERROR_BAD_DOMAIN
+
+
+def test_group_needs_a_device(engine_lib):
+    if engine_lib.lk_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(ca.LkError):
+        ca.HipCorrelationGroup(1)
+
+
+def plain_engine(und, dfm, invariant=True, **kw):
+    e = ca.HipCorrelationEngine(**kw)
+    e.set_batch_invariant(invariant)
+    e.set_undeformed_image(und)
+    e.set_deformed_image(dfm)
+    return e
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("invariant", [True, False])
+def test_one_device_group_equals_the_engine(speckle512, invariant):
+    """n = 1 goes through ncclCommInitAll, ncclBroadcast and ncclAllGather like any other size."""
+    und, dfm = speckle512
+    e = plain_engine(und, dfm, invariant)
+    e.set_rect_grid(24.0, 24.0, 487.0, 487.0, 21, 19)
+    e.commit_sectors()
+    want = e.correlate_all(np.zeros(6, np.float32))
+    e.close()
+    g = ca.HipCorrelationGroup(1)
+    g.for_each_engine("lk_set_batch_invariant", int(invariant))
+    g.set_image(ca.IMG_UND, und)
+    g.set_image(ca.IMG_DEF, dfm)
+    g.set_rect_grid(24.0, 24.0, 487.0, 487.0, 21, 19)
+    g.commit_sectors()
+    assert g.size == 1 and g.n_sectors == 399 and g.shard(0) == (0, 399)
+    got = g.correlate_all(np.zeros(6, np.float32))
+    assert got.tobytes() == want.tobytes()
+    st = g.stats()
+    assert st["sectors"] == 399 and st["point_iterations"] > 399 * 3
+    # records left on the device, fetched later
+    g.correlate_all(np.zeros(6, np.float32), fetch=False)
+    g.synchronize()
+    g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ranks", [2, 3, 5])
+def test_group_of_several_ranks_equals_the_engine(oracle, speckle512, n_ranks):
+    und, dfm = speckle512
+    # a grid whose size is not a multiple of the rank count, then individually registered sectors of three kinds
+    e = plain_engine(und, dfm)
+    e.set_rect_grid(24.0, 24.0, 487.0, 487.0, 13, 11)
+    e.commit_sectors()
+    rng = np.random.default_rng(4)
+    guesses = (rng.standard_normal((143, 6)) * [0.3, 0.3, 1e-3, 1e-3, 1e-3, 1e-3]).astype(np.float32)
+    want_grid = e.correlate_all(guesses)
+    e.clear_sectors()
+    pts = oracle.rect_points(300, 310, 330, 345)
+    regs = []
+    for s in range(17):
+        if s % 3 == 0:
+            regs.append(("rect", (20 + 25 * s, 30 + 20 * s, 60 + 25 * s, 75 + 20 * s)))
+        elif s % 3 == 1:
+            regs.append(("annular", (40.0 + s, 30.0, 0.3 * s, 1.1, 256.0, 250.0, 4)))
+        else:
+            regs.append(("points", (pts + np.float32([s, -s]), (315.0 + s, 327.0 - s) if s % 2 else None)))
+    for s, (kind, a) in enumerate(regs):
+        if kind == "rect":
+            e.resetPolygon_rect(s, *a)
+        elif kind == "annular":
+            e.resetPolygon_annular(s, *a)
+        else:
+            e.set_sector_points(s, a[0], center=a[1])
+    e.commit_sectors()
+    want_mixed = e.correlate_all(np.zeros(6, np.float32))
+    e.close()
+
+    g = ca.HipCorrelationGroup([0] * n_ranks)
+    g.for_each_engine("lk_set_batch_invariant", 1)
+    g.set_image(ca.IMG_UND, und)
+    g.set_image(ca.IMG_DEF, dfm)
+    g.set_rect_grid(24.0, 24.0, 487.0, 487.0, 13, 11)
+    g.commit_sectors()
+    assert [g.shard(r) for r in range(n_ranks)] == [shard_range(143, r, n_ranks) for r in range(n_ranks)]
+    got = g.correlate_all(guesses)
+    assert got.tobytes() == want_grid.tobytes()
+    assert g.stats()["sectors"] == 143
+    for s, (kind, a) in enumerate(regs):
+        if kind == "rect":
+            g.set_sector_rect(s, *a)
+        elif kind == "annular":
+            g.set_sector_annular(s, *a)
+        else:
+            g.set_sector_points(s, a[0], center=a[1])
+    g.commit_sectors()
+    assert g.correlate_all(np.zeros(6, np.float32)).tobytes() == want_mixed.tobytes()
+    g.close()
+
+
+@pytest.mark.gpu
+def test_group_tracks_a_constant_velocity_sequence():
+    """BASELINE config 4's shape: the guess history lives with the engine that owns the sector; per frame
+    only the new image goes out and the records come back (und fixed, def <- nxt rotation)."""
+    frames = ca.speckle.speckle_sequence(384, 384, 5, velocity=(0.8, -0.4), dilation=1e-4, seed=9)
+    gg, centre = np.zeros(6, np.float32), (191.5, 191.5)
+
+    def run(target, is_group):
+        out = []
+        target.set_image(ca.IMG_UND, frames[0]) if is_group else target.set_undeformed_image(frames[0])
+        target.set_image(ca.IMG_DEF, frames[1]) if is_group else target.set_deformed_image(frames[1])
+        target.set_rect_grid(24.0, 24.0, 359.0, 359.0, 14, 15)
+        target.commit_sectors()
+        for k in range(4):
+            if k > 0:
+                if is_group:
+                    target.set_image(ca.IMG_NXT, frames[k + 1])
+                    target.rotate_def_from_nxt()
+                else:
+                    target.set_next_image(frames[k + 1])
+                    target.makeDefPyramidFromNxt()
+            target.adjust_initial_guess(k, True, gg, centre)
+            out.append(target.correlate_all(None))
+        return out
+
+    e = ca.HipCorrelationEngine()
+    e.set_batch_invariant(True)
+    want = run(e, False)
+    e.close()
+    g = ca.HipCorrelationGroup([0, 0, 0])
+    g.for_each_engine("lk_set_batch_invariant", 1)
+    got = run(g, True)
+    g.close()
+    for k in range(4):
+        assert got[k].tobytes() == want[k].tobytes(), k
+    u = np.array([np.median(r["p"][:, 0]) for r in want])
+    assert np.allclose(u, 0.8 * np.arange(1, 5), atol=0.05)     # the sequence really moves 0.8 px per frame
+
+
+@pytest.mark.gpu
+def test_sharded_correlator_device_path_on_one_rank(speckle512):
+    """correlation_amd/distributed.py with a torch device: frames and records stay in HBM, torch / RCCL and
+    the engine share one HIP stream (the broadcast, the pyramid launch that reads the broadcast tensor,
+    the solve and the gather are ordered by that stream)."""
+    import torch
+    from correlation_amd.distributed import ShardedCorrelator
+    und, dfm = speckle512
+    e = plain_engine(und, dfm)
+    e.set_rect_grid(24.0, 24.0, 487.0, 487.0, 12, 9)
+    e.commit_sectors()
+    want = e.correlate_all(np.zeros(6, np.float32))
+    e.close()
+    e = ca.HipCorrelationEngine()
+    e.set_batch_invariant(True)
+    sc = ShardedCorrelator(e, None, torch.device("cuda", 0))
+    for rep in range(3):     # frames replaced while earlier launches may still be queued
+        sc.broadcast_frame(ca.IMG_UND, und if rep == 2 else dfm)
+        sc.broadcast_frame(ca.IMG_DEF, dfm if rep == 2 else und)
+    sc.set_rect_grid(24.0, 24.0, 487.0, 487.0, 12, 9)
+    got = sc.correlate_all(np.zeros(6, np.float32))
+    assert got.tobytes() == want.tobytes()
+    e.close()
