@@ -76,6 +76,28 @@ struct LkSolveArgs {
   int max_iters;
 };
 
+// ROI -> level-0 sample lists on the device (cudaPolygon's mask + compaction, cuda_polygon.cuh:180-292,
+// cuda_polygon.cu:589-627, with the CPU engine's predicates and sample order: SURVEY.md 8a-a10).
+// The work is cut into TILES whose outputs are consecutive in the final list:
+//   annular sector  candidates = the bounding box walked x outer / y inner (manager_class.cpp:902-925),
+//                   1024 candidates per tile, the predicate (:907-918) keeps some of them;
+//   blob sector     one tile per scan line of each flat-sided half triangle, in the ear clipper's
+//                   order (polygon_class.cpp:283-403); every pixel of the line is kept.
+struct LkRoiSector {
+  int kind;               // 0 annular, 1 blob
+  int x0, y0, x1, y1;     // annular: candidates fx in [x0, x1), j in [y0, y1)
+  float cx, cy, ri2, ro2; // annular: centre, squared radii
+  float q00x, q01x, q10x, q11x, q00y, q01y, q10y, q11y; // annular: wedge corners (outer ones with the 1.2 "sag")
+  int as;                 // annular: 1 = full ring (no wedge test)
+  int flat_begin, flat_count; // blob: its half triangles in the flat table
+};
+struct LkRoiFlat { // one flat-sided half triangle: rows j0 .. j1-1, pixels ceil(ls*j+li) .. ceil(rs*j+ri)-1
+  float ls, li, rs, ri;
+  int j0, j1;
+  int row_begin; // index of its first scan line among the sector's tiles
+};
+constexpr int kLkRoiTile = 1024;
+
 struct LkRewarpArgs { // level-0 sample lists moved by the last level-0 evaluation's parameters (or by an offset)
   const float2 *src_xy;    // lists before (explicit sectors)
   const uint32_t *src_off; // [S+1]

@@ -45,8 +45,13 @@ int lk_decimate_tiles(uint32_t n_max);
 hipError_t lk_launch_decimate(const float2 *xy_prev, const uint32_t *off_prev, const uint32_t *n_prev, uint32_t n_max,
                               int level_delta, int n_sectors, uint32_t *pos, uint32_t *tiles, float2 *xy_out,
                               uint32_t *off_out, uint32_t *n_out, hipStream_t st);
+hipError_t lk_launch_roi_count(const LkRoiSector *sectors, const LkRoiFlat *flats, const uint32_t *tile_begin, int n_sectors,
+                               uint32_t n_tiles, uint32_t *tiles, uint32_t *n_out, hipStream_t st);
+hipError_t lk_launch_roi_fill(const LkRoiSector *sectors, const LkRoiFlat *flats, const uint32_t *tile_begin, int n_sectors,
+                              uint32_t n_tiles, const uint32_t *tiles, float2 *xy, uint32_t *off, hipStream_t st);
 hipError_t lk_launch_stale_iterations(lk_result *r, int n, const int *carry_in, int *carry_out, hipStream_t st);
 hipError_t lk_launch_mean_center(const float2 *xy, const uint32_t *off, int n_sectors, float2 *center, hipStream_t st);
+hipError_t lk_launch_mean_center_int(const float2 *xy, const uint32_t *off, int n_sectors, float2 *center, hipStream_t st);
 
 namespace {
 
@@ -88,7 +93,25 @@ struct HostSector {
   bool has_center = false; // the solve centre was given (rectangular path) rather than the samples' mean
   bool set = false;
   bool fresh = true; // registered (lk_set_sector_*) since the last commit: its sequence state starts from zero
-  int n0() const { return is_rect ? (x1 - x0 + 1) * (y1 - y0 + 1) : (int)(xy.size() / 2); }
+  // Annular and blob sectors are registered by their DESCRIPTION; the sample list is made by the
+  // device mask at commit (lk_roi_tile_kernel) or, on demand, by the host scan (realize()).
+  int lazy = 0;      // 0: xy / rectangle are the sector; 1: annular geometry `ag`; 2: blob half triangles `flats`
+  lkroi::AnnularGeometry ag;
+  std::vector<lkroi::BlobPolygon::Flat> flats;
+  int n0_device = 0; // lazy sectors after a device commit: their sample count
+  int n0() const { return is_rect ? (x1 - x0 + 1) * (y1 - y0 + 1) : (lazy ? n0_device : (int)(xy.size() / 2)); }
+  void realize() {   // the host scan of a lazily registered sector: same samples, same order
+    if (!lazy)
+      return;
+    xy.clear();
+    if (lazy == 1)
+      lkroi::annular_points(ag, xy);
+    else
+      lkroi::BlobPolygon::fill(flats, xy);
+    if (!xy.empty())
+      lkroi::mean_center(xy.data(), (int)(xy.size() / 2), cx, cy); // correlation_class.cpp:337-339
+    lazy = 0;
+  }
   std::vector<float> points() const { // level-0 list in the CPU engine's order
     if (!is_rect)
       return xy;
@@ -191,6 +214,9 @@ struct lk_engine {
   bool lists_on_device = false, backup_on_device = false;
   DevBuf<float2> d_xy0_alt;
   DevBuf<uint32_t> d_off0_alt, d_pos, d_tiles, d_level_total;
+  DevBuf<LkRoiSector> d_roi_sectors; // device ROI masks (commit of annular / blob sectors)
+  DevBuf<LkRoiFlat> d_roi_flats;
+  DevBuf<uint32_t> d_roi_tile_begin;
   std::vector<float> h_center_prev, h_offsets;
   DevBuf<float2> d_offsets;
   int S = 0;
@@ -307,6 +333,9 @@ void lk_destroy(lk_engine *e) {
   e->d_pos.release();
   e->d_tiles.release();
   e->d_level_total.release();
+  e->d_roi_sectors.release();
+  e->d_roi_flats.release();
+  e->d_roi_tile_begin.release();
   e->d_offsets.release();
   e->d_guess.release();
   e->d_last_p.release();
@@ -623,6 +652,7 @@ static int lists_from_device(lk_engine *e, const float2 *d_xy0, const std::vecto
     HostSector &h = out[s];
     h.xy.assign(xy.begin() + 2 * (size_t)e->h_off[0][s], xy.begin() + 2 * (size_t)e->h_off[0][s + 1]);
     h.is_rect = false;
+    h.lazy = 0;
     h.cx = centers[2 * s];
     h.cy = centers[2 * s + 1];
   }
@@ -650,6 +680,13 @@ int lk_clear_sectors(lk_engine *e) {
   return LK_ERROR_NONE;
 }
 
+// LK_HOST_ROI=1 (test / comparison hook, read per call): annular and blob sectors are rasterised by
+// the host scan at registration, as in round 1, instead of by the device mask at commit
+static bool host_roi() {
+  const char *f = std::getenv("LK_HOST_ROI");
+  return f && std::atoi(f) != 0;
+}
+
 static HostSector *sector_slot(lk_engine *e, int sector) {
   if (sector < 0 || materialize_host(e))
     return nullptr;
@@ -657,6 +694,7 @@ static HostSector *sector_slot(lk_engine *e, int sector) {
     e->hs.resize((size_t)sector + 1);
   e->committed = false;
   e->hs[(size_t)sector].fresh = true;
+  e->hs[(size_t)sector].lazy = 0; // (annular / blob registration sets it again)
   return &e->hs[(size_t)sector];
 }
 
@@ -723,9 +761,15 @@ int lk_set_sector_annular(lk_engine *e, int sector, float r, float dr, float a, 
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sector_annular: bad sector index");
   s->xy.clear();
   s->is_rect = false;
-  if (!lkroi::annular_points(r, dr, a, da, cx, cy, as, s->xy) || s->xy.empty())
-    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sector_annular: empty sector");
-  lkroi::mean_center(s->xy.data(), (int)(s->xy.size() / 2), s->cx, s->cy); // correlation_class.cpp:337-339
+  s->flats.clear();
+  if (!lkroi::annular_geometry(r, dr, a, da, cx, cy, as, s->ag))
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sector_annular: bad sector description");
+  s->lazy = 1; // the samples come from the device mask at commit (or from realize())
+  if (host_roi()) {
+    s->realize();
+    if (s->xy.empty())
+      return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sector_annular: empty sector");
+  }
   s->has_center = false;
   s->set = true;
   return LK_ERROR_NONE;
@@ -738,8 +782,9 @@ int lk_set_sectors_annular(lk_engine *e, int first_sector, int count, const floa
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sectors_annular: bad arguments");
   if (!sector_slot(e, first_sector + count - 1)) // sizes the table once, before the threads
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sectors_annular: bad sector range");
+  const bool on_host = host_roi();
   const unsigned hw = std::thread::hardware_concurrency();
-  const int workers = std::max(1, std::min({count, 16, (int)(hw ? hw : 1)}));
+  const int workers = on_host ? std::max(1, std::min({count, 16, (int)(hw ? hw : 1)})) : 1;
   std::vector<int> empty((size_t)workers, 0);
   auto work = [&](int w) {
     for (int k = w; k < count; k += workers) { // interleaved: neighbouring rings have similar sizes
@@ -747,11 +792,20 @@ int lk_set_sectors_annular(lk_engine *e, int first_sector, int count, const floa
       HostSector &s = e->hs[(size_t)(first_sector + k)];
       s.xy.clear();
       s.is_rect = false;
-      if (!lkroi::annular_points(q[0], q[1], q[2], q[3], q[4], q[5], as, s.xy) || s.xy.empty()) {
+      s.flats.clear();
+      s.fresh = true;
+      if (!lkroi::annular_geometry(q[0], q[1], q[2], q[3], q[4], q[5], as, s.ag)) {
         empty[(size_t)w] = 1;
         continue;
       }
-      lkroi::mean_center(s.xy.data(), (int)(s.xy.size() / 2), s.cx, s.cy); // correlation_class.cpp:337-339
+      s.lazy = 1; // the device mask makes the list at commit; LK_HOST_ROI=1: the host scan, here
+      if (on_host) {
+        s.realize();
+        if (s.xy.empty()) {
+          empty[(size_t)w] = 1;
+          continue;
+        }
+      }
       s.has_center = false;
       s.set = true;
     }
@@ -776,11 +830,21 @@ int lk_set_sector_blob(lk_engine *e, int sector, const float *contour_xy, int n_
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sector_blob: bad arguments");
   s->xy.clear();
   s->is_rect = false;
-  if (!lkroi::BlobPolygon::inside_points(contour_xy, n_vertices, s->xy) || s->xy.empty()) {
-    s->set = false;
-    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sector_blob: contour is not a simple polygon");
+  s->flats.clear();
+  s->lazy = 0;
+  if (host_roi()) { // round 1's path: ear clipping + scan fill on a few host threads
+    if (!lkroi::BlobPolygon::inside_points(contour_xy, n_vertices, s->xy) || s->xy.empty()) {
+      s->set = false;
+      return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sector_blob: contour is not a simple polygon");
+    }
+    lkroi::mean_center(s->xy.data(), (int)(s->xy.size() / 2), s->cx, s->cy);
+  } else { // the ear clipper stays on the host (O(vertices^2)); the fill is the device mask's, at commit
+    if (!lkroi::BlobPolygon::flat_triangles(contour_xy, n_vertices, s->flats) || s->flats.empty()) {
+      s->set = false;
+      return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_sector_blob: contour is not a simple polygon");
+    }
+    s->lazy = 2;
   }
-  lkroi::mean_center(s->xy.data(), (int)(s->xy.size() / 2), s->cx, s->cy);
   s->has_center = false;
   s->set = true;
   return LK_ERROR_NONE;
@@ -830,6 +894,132 @@ static int refresh_starved(lk_engine *e) {
   return LK_ERROR_NONE;
 }
 
+static int level0_count(const lk_engine *e, int s) { // samples of a sector at level 0, from the committed tables
+  const int4 r = e->h_rect[0][(size_t)s];
+  return r.z > 0 ? r.w : (int)(e->h_off[0][(size_t)s + 1] - e->h_off[0][(size_t)s]);
+}
+
+// Device ROI masks: every sector of the domain is annular or a blob and registered by description.
+// Replaces cudaPolygon{Annular,Blob}'s thrust rasterise + remove_if (cuda_polygon.cuh:180-292,
+// cuda_polygon.cu:589-627) with the CPU engine's predicates and sample order.  Leaves d_xy / d_off
+// of every level, d_center, h_off, h_center and zeroed rectangles behind; the lists stay on the device.
+static int build_lists_roi_device(lk_engine *e, const std::vector<int> &levels) {
+  Range range_("lk:roi masks");
+  const int S = (int)e->hs.size();
+  hipStream_t st = e->stream;
+  std::vector<LkRoiSector> sec((size_t)S);
+  std::vector<LkRoiFlat> flats;
+  std::vector<uint32_t> tile_begin((size_t)S + 1, 0u);
+  uint64_t tiles = 0;
+  bool non_negative = true; // every coordinate the masks can produce is >= 0 and below 2^15 (lk_mean_center_int_kernel)
+  for (int s = 0; s < S; ++s) {
+    const HostSector &h = e->hs[(size_t)s];
+    LkRoiSector &q = sec[(size_t)s];
+    std::memset(&q, 0, sizeof(q));
+    tile_begin[(size_t)s] = (uint32_t)tiles;
+    if (h.lazy == 1) {
+      const lkroi::AnnularGeometry &g = h.ag;
+      q.kind = 0;
+      q.x0 = g.x0, q.y0 = g.y0, q.x1 = g.x1, q.y1 = g.y1;
+      q.cx = g.cx, q.cy = g.cy, q.ri2 = g.ri2, q.ro2 = g.ro2;
+      q.q00x = g.q00x, q.q01x = g.q01x, q.q10x = g.q10x, q.q11x = g.q11x;
+      q.q00y = g.q00y, q.q01y = g.q01y, q.q10y = g.q10y, q.q11y = g.q11y;
+      q.as = g.as;
+      const int64_t w = std::max(0, g.x1 - g.x0), hh = std::max(0, g.y1 - g.y0);
+      if (w * hh >= (int64_t)1 << 31)
+        return e->fail(LK_ERROR_BAD_DOMAIN, "lk_commit_sectors: annular sector bounding box too large");
+      q.x1 = q.x0 + (int)w, q.y1 = q.y0 + (int)hh;
+      // kept samples lie strictly inside the outer circle (and inside the bounding box)
+      non_negative = non_negative && std::max((float)q.x0, g.cx - g.ro) >= 0.f && std::max((float)q.y0, g.cy - g.ro) >= 0.f &&
+                     q.x1 < (1 << 15) && q.y1 < (1 << 15);
+      tiles += (uint64_t)((w * hh + kLkRoiTile - 1) / kLkRoiTile);
+    } else {
+      q.kind = 1;
+      q.flat_begin = (int)flats.size();
+      q.flat_count = (int)h.flats.size();
+      uint64_t rows = 0;
+      for (const lkroi::BlobPolygon::Flat &f : h.flats) {
+        LkRoiFlat d;
+        d.ls = f.ls, d.li = f.li, d.rs = f.rs, d.ri = f.ri, d.j0 = f.j0, d.j1 = f.j1;
+        d.row_begin = (int)rows;
+        rows += (uint64_t)(f.j1 - f.j0);
+        flats.push_back(d);
+        // pixel range of its two end rows (the edges are straight: the extremes are there)
+        for (int j : {f.j0, f.j1 - 1}) {
+          const float a = std::ceil(f.ls * (float)j + f.li), b = std::ceil(f.rs * (float)j + f.ri);
+          non_negative = non_negative && j >= 0 && j < (1 << 15) && a >= 0.f && b < 32768.f;
+        }
+      }
+      tiles += rows;
+    }
+    if (tiles >= (uint64_t)1 << 31)
+      return e->fail(LK_ERROR_BAD_DOMAIN, "lk_commit_sectors: region of interest too large for the device mask");
+  }
+  tile_begin[(size_t)S] = (uint32_t)tiles;
+  const uint32_t n_tiles = (uint32_t)tiles;
+  if (n_tiles == 0)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_commit_sectors: empty region of interest");
+  HIPCHK(e->d_roi_sectors.ensure((size_t)S));
+  HIPCHK(e->d_roi_flats.ensure(flats.size() + 1));
+  HIPCHK(e->d_roi_tile_begin.ensure((size_t)S + 1));
+  HIPCHK(hipMemcpyAsync(e->d_roi_sectors.p, sec.data(), (size_t)S * sizeof(LkRoiSector), hipMemcpyHostToDevice, st));
+  if (!flats.empty())
+    HIPCHK(hipMemcpyAsync(e->d_roi_flats.p, flats.data(), flats.size() * sizeof(LkRoiFlat), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(e->d_roi_tile_begin.p, tile_begin.data(), ((size_t)S + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  HIPCHK(e->d_level_total.ensure(LK_MAX_LEVELS));
+  // (the tile table may be larger than the decimation's: both share d_tiles)
+  HIPCHK(e->d_tiles.ensure(4 * (size_t)n_tiles + 2)); // (also enough for the decimation passes below in all but pathological blobs)
+  HIPCHK(lk_launch_roi_count(e->d_roi_sectors.p, e->d_roi_flats.p, e->d_roi_tile_begin.p, S, n_tiles, e->d_tiles.p,
+                             e->d_level_total.p, st));
+  uint32_t total = 0;
+  HIPCHK(hipMemcpyAsync(&total, e->d_level_total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st)); // the list buffers are sized by the count
+  if (total == 0)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_commit_sectors: empty region of interest");
+  for (int l : levels) {
+    HIPCHK(e->d_xy[l].ensure((size_t)total + 1));
+    HIPCHK(e->d_off[l].ensure((size_t)S + 1));
+    HIPCHK(e->d_rect[l].ensure((size_t)S));
+    HIPCHK(hipMemsetAsync(e->d_rect[l].p, 0, (size_t)S * sizeof(int4), st));
+    e->h_rect[l].assign((size_t)S, make_int4(0, 0, 0, 0));
+    e->h_off[l].assign((size_t)S + 1, 0u);
+  }
+  HIPCHK(lk_launch_roi_fill(e->d_roi_sectors.p, e->d_roi_flats.p, e->d_roi_tile_begin.p, S, n_tiles, e->d_tiles.p,
+                            e->d_xy[0].p, e->d_off[0].p, st));
+  HIPCHK(hipMemcpyAsync(e->h_off[0].data(), e->d_off[0].p, ((size_t)S + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  // coarser levels: pyramid_class.cpp:289-323 for all sectors at once (the kernels of lk_rewarp_sectors)
+  HIPCHK(e->d_pos.ensure((size_t)total + 1));
+  HIPCHK(e->d_tiles.ensure((size_t)std::max<uint32_t>(n_tiles, (uint32_t)lk_decimate_tiles(total)) + 2));
+  for (size_t li = 1; li < levels.size(); ++li) {
+    const int l = levels[li], pl = levels[li - 1];
+    HIPCHK(lk_launch_decimate(e->d_xy[pl].p, e->d_off[pl].p, e->d_level_total.p + pl, total, l - pl, S, e->d_pos.p,
+                              e->d_tiles.p, e->d_xy[l].p, e->d_off[l].p, e->d_level_total.p + l, st));
+    HIPCHK(hipMemcpyAsync(e->h_off[l].data(), e->d_off[l].p, ((size_t)S + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  }
+  // centres: the float mean of the samples in list order (correlation_class.cpp:337-339)
+  HIPCHK(e->d_center.ensure((size_t)S));
+  e->h_center.resize(2 * (size_t)S);
+  // (the mask's coordinates are integers; non-negative ones - the ROI lies in the image - let the
+  // chain be evaluated in parallel, see lk_mean_center_int_kernel)
+  if (non_negative)
+    HIPCHK(lk_launch_mean_center_int(e->d_xy[0].p, e->d_off[0].p, S, e->d_center.p, st));
+  else
+    HIPCHK(lk_launch_mean_center(e->d_xy[0].p, e->d_off[0].p, S, e->d_center.p, st));
+  HIPCHK(hipMemcpyAsync(e->h_center.data(), e->d_center.p, 2 * (size_t)S * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  for (int s = 0; s < S; ++s) {
+    HostSector &h = e->hs[(size_t)s];
+    h.n0_device = (int)(e->h_off[0][(size_t)s + 1] - e->h_off[0][(size_t)s]);
+    if (h.n0_device == 0)
+      return e->fail(LK_ERROR_BAD_DOMAIN, "lk_commit_sectors: sector " + std::to_string(s) + " is empty");
+    h.cx = e->h_center[2 * (size_t)s];
+    h.cy = e->h_center[2 * (size_t)s + 1];
+  }
+  e->lists_on_device = true;
+  e->backup_on_device = false;
+  return LK_ERROR_NONE;
+}
+
 // keep_state: a re-commit after the sample lists moved (Lagrangian descriptions) keeps the
 // sequence state of the sectors (guess history, last results)
 static int commit_impl(lk_engine *e, bool keep_state) {
@@ -850,7 +1040,30 @@ static int commit_impl(lk_engine *e, bool keep_state) {
   std::vector<int> levels{0};
   for (int l = first; l <= cfg.py_stop; l += cfg.py_step)
     levels.push_back(l);
+  // Annular / blob sectors registered by description: the device mask makes every list (level 0 by
+  // lk_roi_tile_kernel, the coarser levels by the order-preserving compaction, centres by
+  // lk_mean_center_kernel); only offsets and centres come back.  A domain that mixes them with
+  // rectangles or explicit lists, or LK_HOST_ROI=1, takes the host scans instead (same lists).
+  bool any_lazy = false, all_lazy = true;
+  for (int s = 0; s < S; ++s) {
+    any_lazy = any_lazy || e->hs[(size_t)s].lazy != 0;
+    all_lazy = all_lazy && e->hs[(size_t)s].lazy != 0;
+  }
+  const bool device_roi = any_lazy && all_lazy && !host_roi();
+  if (any_lazy && !device_roi)
+    for (int s = 0; s < S; ++s)
+      e->hs[(size_t)s].realize();
+  if (any_lazy && !device_roi)
+    for (int s = 0; s < S; ++s)
+      if (!e->hs[(size_t)s].is_rect && e->hs[(size_t)s].xy.empty())
+        return e->fail(LK_ERROR_BAD_DOMAIN, "lk_commit_sectors: sector " + std::to_string(s) + " is empty");
+  if (device_roi) {
+    int rc = build_lists_roi_device(e, levels);
+    if (rc)
+      return rc;
+  }
   std::vector<std::vector<float>> cat(LK_MAX_LEVELS);
+  if (!device_roi) {
   for (int l = 0; l < LK_MAX_LEVELS; ++l)
     e->h_off[l].assign(1, 0u);
   size_t total0 = 0;
@@ -931,6 +1144,8 @@ static int commit_impl(lk_engine *e, bool keep_state) {
     }
     HIPCHK(hipStreamSynchronize(e->stream));
   }
+  e->lists_on_device = false;
+  } // !device_roi
   HIPCHK(e->d_center.ensure((size_t)S));
   HIPCHK(hipMemcpy(e->d_center.p, e->h_center.data(), 2 * (size_t)S * sizeof(float), hipMemcpyHostToDevice));
   // Per-sector sequence state (guess history, last record, last evaluated parameters) survives a
@@ -970,7 +1185,7 @@ static int commit_impl(lk_engine *e, bool keep_state) {
   e->h_class.assign((size_t)S, 0);
   size_t cnt[kNumClasses] = {0, 0, 0, 0, 0, 0}, tot[kNumClasses] = {0, 0, 0, 0, 0, 0};
   for (int s = 0; s < S; ++s) {
-    int n0 = e->hs[(size_t)s].n0(), c = size_class(n0);
+    int n0 = level0_count(e, s), c = size_class(n0);
     e->h_class[(size_t)s] = c;
     cnt[c]++;
     tot[c] += (size_t)n0;
@@ -1025,7 +1240,7 @@ static int commit_impl(lk_engine *e, bool keep_state) {
     for (int s = 0; s < S; ++s)
       if (e->h_class[(size_t)s] == kTeamClass) {
         ++n_team;
-        n0_max = std::max(n0_max, e->hs[(size_t)s].n0());
+        n0_max = std::max(n0_max, level0_count(e, s));
       }
     if (n_team) {
       int w = force_team >= 1 ? force_team : (n0_max + kTeamMinSamples - 1) / kTeamMinSamples;
@@ -1283,6 +1498,8 @@ static int rewarp_on_device(lk_engine *e, const float *centers_xy, const float *
     e->backup_on_device = false;
   }
   e->h_center_prev = e->h_center;
+  for (HostSector &h : e->hs) // (descriptions of annular / blob sectors no longer describe the moved lists)
+    h.lazy = 0;
   std::swap(e->d_xy[0], e->d_xy0_alt);
   if (!explicit_already)
     std::swap(e->d_off[0], e->d_off0_alt);
@@ -1418,10 +1635,22 @@ int lk_sector_count(const lk_engine *e) { return e ? (e->committed ? e->S : (int
 int lk_get_sector_info(lk_engine *e, int sector, int *n_points, float *cx, float *cy) {
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
-  if (int rc = materialize_host(e))
-    return rc;
   if (sector < 0 || (size_t)sector >= e->hs.size() || !e->hs[(size_t)sector].set)
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_sector_info: unknown sector");
+  if (e->lists_on_device && e->committed) { // device-built lists: counts and centres are on the host already
+    const size_t q = (size_t)sector;
+    const int4 r0 = e->h_rect[0][q];
+    if (n_points)
+      *n_points = r0.z > 0 ? r0.w : (int)(e->h_off[0][q + 1] - e->h_off[0][q]);
+    if (cx)
+      *cx = e->h_center[2 * q];
+    if (cy)
+      *cy = e->h_center[2 * q + 1];
+    return LK_ERROR_NONE;
+  }
+  if (int rc = materialize_host(e))
+    return rc;
+  e->hs[(size_t)sector].realize();
   const HostSector &s = e->hs[(size_t)sector];
   if (n_points)
     *n_points = s.n0();
@@ -1448,10 +1677,22 @@ int lk_get_sector_level_count(lk_engine *e, int sector, int level, int *n) {
 int lk_get_und_xy(lk_engine *e, int sector, float *xy, int cap, int *count) {
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
-  if (int rc = materialize_host(e))
-    return rc;
   if (sector < 0 || (size_t)sector >= e->hs.size() || !e->hs[(size_t)sector].set)
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_und_xy: unknown sector");
+  if (e->lists_on_device && e->committed && e->h_rect[0][(size_t)sector].z == 0) { // that sector's list only
+    const uint32_t b = e->h_off[0][(size_t)sector], n = e->h_off[0][(size_t)sector + 1] - b;
+    if (count)
+      *count = (int)n;
+    if (xy && cap > 0) {
+      HIPCHK(hipSetDevice(e->cfg.device));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      HIPCHK(hipMemcpy(xy, e->d_xy[0].p + b, sizeof(float2) * (size_t)std::min((int)n, cap), hipMemcpyDeviceToHost));
+    }
+    return LK_ERROR_NONE;
+  }
+  if (int rc = materialize_host(e))
+    return rc;
+  e->hs[(size_t)sector].realize();
   const HostSector &s = e->hs[(size_t)sector];
   int n = s.n0();
   if (count)

@@ -2449,6 +2449,113 @@ __global__ void lk_decimate_offsets_kernel(const uint32_t *off_prev, const uint3
   off_new[s] = o < n ? tile_first[o / kScanTile] + (pos[o] & 0x7fffffffu) : tile_first[n_tiles];
 }
 
+// ---- ROI masks on the device (see LkRoiSector in lk_device.hpp) ---------------------------------
+// Which sector a tile belongs to: the last s with tile_begin[s] <= t (wavefront-uniform search).
+__device__ __forceinline__ int roi_sector_of_tile(const uint32_t *tile_begin, int n_sectors, uint32_t t) {
+  int lo = 0, hi = n_sectors;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_begin[mid] <= t)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// get_inside_points_annularDomain's test for candidate (fx, j) - manager_class.cpp:907-918, the same
+// float operations in the same order as lkroi::annular_points (contraction is off in both builds)
+__device__ __forceinline__ bool roi_annular_keeps(const LkRoiSector &q, float fx, int j) {
+  const float ex = fx - q.cx, ey = (float)j - q.cy;
+  const float r2 = ex * ex + ey * ey;
+  if (!(r2 > q.ri2 && r2 < q.ro2))
+    return false;
+  const float w1 = (q.q11x - fx) * (q.q01y - q.q11y) - (q.q11y - (float)j) * (q.q01x - q.q11x);
+  const float w2 = (q.q00x - fx) * (q.q10y - q.q00y) - (q.q00y - (float)j) * (q.q10x - q.q00x);
+  return w1 * w2 > 0.f || q.as == 1;
+}
+
+__device__ __forceinline__ void roi_blob_row(const LkRoiSector &q, const LkRoiFlat *flats, uint32_t row, int &j, int &i0,
+                                             int &i1) {
+  int lo = q.flat_begin, hi = q.flat_begin + q.flat_count; // last flat with row_begin <= row
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((uint32_t)flats[mid].row_begin <= row)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  const LkRoiFlat f = flats[lo];
+  j = f.j0 + (int)(row - (uint32_t)f.row_begin);
+  i0 = (int)ceilf(f.ls * (float)j + f.li); // polygon_class.cpp:389-391
+  i1 = (int)ceilf(f.rs * (float)j + f.ri);
+}
+
+// FILL = false: tile_count[t] = samples the tile keeps.  FILL = true: the samples, at tile_first[t].
+template <bool FILL>
+__global__ void __launch_bounds__(kScanThreads) lk_roi_tile_kernel(const LkRoiSector *sectors, const LkRoiFlat *flats,
+                                                                   const uint32_t *tile_begin, int n_sectors,
+                                                                   uint32_t *tile_count, const uint32_t *tile_first,
+                                                                   float2 *out) {
+  __shared__ uint32_t lds[kScanThreads / kWave];
+  const uint32_t t = blockIdx.x;
+  const int s = roi_sector_of_tile(tile_begin, n_sectors, t);
+  const LkRoiSector q = sectors[s];
+  const uint32_t local = t - tile_begin[s];
+  if (q.kind == 1) { // one scan line of a blob
+    int j, i0, i1;
+    roi_blob_row(q, flats, local, j, i0, i1);
+    if constexpr (!FILL) {
+      if (threadIdx.x == 0)
+        tile_count[t] = i1 > i0 ? (uint32_t)(i1 - i0) : 0u;
+    } else {
+      float2 *dst = out + tile_first[t];
+      for (int i = i0 + (int)threadIdx.x; i < i1; i += kScanThreads)
+        dst[i - i0] = make_float2((float)i, (float)j);
+    }
+    return;
+  }
+  const int h = q.y1 - q.y0, w = q.x1 - q.x0;
+  const uint32_t n_cand = (uint32_t)w * (uint32_t)h, base = local * (uint32_t)kLkRoiTile + threadIdx.x * kScanItems;
+  bool keep[kScanItems];
+  float fx[kScanItems];
+  int jj[kScanItems];
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    const uint32_t idx = base + k;
+    keep[k] = false;
+    fx[k] = 0.f;
+    jj[k] = 0;
+    if (idx < n_cand) {
+      const uint32_t col = idx / (uint32_t)h; // x outer, y inner
+      fx[k] = (float)(q.x0 + (int)col);
+      jj[k] = q.y0 + (int)(idx - col * (uint32_t)h);
+      keep[k] = roi_annular_keeps(q, fx[k], jj[k]);
+    }
+    cnt += keep[k];
+  }
+  uint32_t total;
+  uint32_t at = block_exclusive_sum(cnt, lds, total);
+  if constexpr (!FILL) {
+    if (threadIdx.x == 0)
+      tile_count[t] = total;
+  } else {
+    float2 *dst = out + tile_first[t];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k)
+      if (keep[k])
+        dst[at++] = make_float2(fx[k], (float)jj[k]);
+  }
+}
+
+// where every sector's list starts: the exclusive prefix at its first tile ([S] = the total)
+__global__ void lk_roi_offsets_kernel(const uint32_t *tile_begin, const uint32_t *tile_first, int n_sectors, uint32_t *off) {
+  const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (s <= n_sectors)
+    off[s] = tile_first[tile_begin[s]];
+}
+
 // Newton_Raphson(p, n, xy) solves about the float mean of the samples, summed in list order
 // (pyramid_class.cpp:325-340).  The order is the reference's, so the additions are one chain
 // per coordinate; what is parallel is the memory side: a wavefront per sector fetches 64
@@ -2510,6 +2617,182 @@ __global__ void lk_stale_iterations_kernel(lk_result *r, int n, const int *carry
   }
   if (s == n - 1)
     *carry_out = v;
+}
+
+// ---- the sequential float mean of an INTEGER sample list, evaluated in parallel, bit for bit ----
+// pyramid_class.cpp:325-340 adds the coordinates into one running float per axis, in list order.
+// For a 4.2 M-sample blob that chain is 4.2 M dependent additions (tens of ms for one wavefront).
+// For device-masked sectors every coordinate is a non-negative integer, and then the chain has
+// structure: the running sum s is an integer-valued float; while s stays in one binade
+// [2^e, 2^(e+1)) its ulp u = 2^(e-23) is fixed and  fl(s + x) = s + u * g  with
+//     g = floor(x / u) + (rem > u/2) + (rem == u/2 and (s/u + floor(x/u)) odd)      (round to nearest even)
+// which depends on s only through the PARITY of s/u.  So a run of samples is a map
+// {parity in} -> {g total, parity out}, and such maps compose associatively: a workgroup scans
+// 32 768 samples per pass (32 per thread, a composition scan over the 1024 threads).  The sum is
+// monotone, so the binade changes at most ~40 times per list; the thread whose run crosses the
+// boundary walks its 32 samples with the exact rounding rule, and the pass restarts behind the
+// crossing with the new ulp.  One workgroup per sector; x first, then y.
+__device__ __forceinline__ long long rne24(long long t) { // the float32 nearest to the integer t >= 0, ties to even
+  if (t < (1ll << 24))
+    return t;
+  const int sh = (63 - __clzll(t)) - 23;
+  const long long u = 1ll << sh, half = u >> 1, r = t & (u - 1);
+  long long q = t >> sh;
+  q += (r > half || (r == half && (q & 1ll))) ? 1 : 0;
+  return q << sh;
+}
+
+struct ParityMap { // {0,1} -> (g, parity): g[p] = units of u added when the run starts at parity p
+  int g0, g1, pn; // pn: bit 0 = parity out for parity in 0, bit 1 = for parity in 1
+};
+__device__ __forceinline__ ParityMap compose(const ParityMap &a, const ParityMap &b) { // a, then b
+  const int pa0 = a.pn & 1, pa1 = (a.pn >> 1) & 1;
+  ParityMap c;
+  c.g0 = a.g0 + (pa0 ? b.g1 : b.g0);
+  c.g1 = a.g1 + (pa1 ? b.g1 : b.g0);
+  c.pn = ((b.pn >> pa0) & 1) | (((b.pn >> pa1) & 1) << 1);
+  return c;
+}
+
+constexpr int kMeanThreads = 1024, kMeanItems = 32; // 32 768 samples per pass; both axes share the loads and barriers
+
+struct AxisPass { // one axis of one pass
+  int sh, p_start;
+  long long s, limit;
+  ParityMap m; // my run
+  __device__ __forceinline__ void begin(long long s_in) {
+    s = s_in;
+    const int ex = s < (1ll << 24) ? 23 : 63 - __clzll(s);
+    sh = ex - 23;                 // ulp = 2^sh
+    limit = 1ll << (ex + 1);      // leaving the binade (or exactness) at this value
+    p_start = (int)((s >> sh) & 1ll);
+    m = ParityMap{0, 0, 2};       // identity
+  }
+  __device__ __forceinline__ void add(int x) {
+    const int shc = sh < 30 ? sh : 30; // (coordinates are below 2^22: beyond that the quotient is 0 anyway)
+    const int qq = x >> shc, r = sh < 30 ? (x & ((1 << shc) - 1)) : x, half = sh < 30 ? ((1 << shc) >> 1) : (1 << 29);
+    const int up = r > half ? 1 : 0, tie = (sh > 0 && r == half) ? 1 : 0;
+    ParityMap one;
+    one.g0 = qq + up + (tie & (qq & 1));       // parity in 0: (0 + qq) odd -> round up
+    one.g1 = qq + up + (tie & ((qq + 1) & 1)); // parity in 1
+    one.pn = (one.g0 & 1) | (((1 + one.g1) & 1) << 1);
+    m = compose(m, one);
+  }
+};
+
+// exclusive composition prefix of `m` over the workgroup's threads; `all` = everybody's composition
+__device__ __forceinline__ ParityMap workgroup_prefix(const ParityMap &m, int *lds3, ParityMap &all) {
+  const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  constexpr int WAVES = kMeanThreads / kWave;
+  ParityMap inc = m;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    ParityMap o;
+    o.g0 = __shfl_up(inc.g0, d, kWave);
+    o.g1 = __shfl_up(inc.g1, d, kWave);
+    o.pn = __shfl_up(inc.pn, d, kWave);
+    if (lane >= d)
+      inc = compose(o, inc);
+  }
+  if (lane == kWave - 1) {
+    lds3[3 * wave] = inc.g0;
+    lds3[3 * wave + 1] = inc.g1;
+    lds3[3 * wave + 2] = inc.pn;
+  }
+  __syncthreads();
+  ParityMap before{0, 0, 2};
+  all = ParityMap{0, 0, 2};
+  for (int w = 0; w < WAVES; ++w) {
+    const ParityMap t{lds3[3 * w], lds3[3 * w + 1], lds3[3 * w + 2]};
+    if (w < wave)
+      before = compose(before, t);
+    all = compose(all, t);
+  }
+  ParityMap o;
+  o.g0 = __shfl_up(inc.g0, 1, kWave);
+  o.g1 = __shfl_up(inc.g1, 1, kWave);
+  o.pn = __shfl_up(inc.pn, 1, kWave);
+  return lane == 0 ? before : compose(before, o);
+}
+
+__global__ void __launch_bounds__(kMeanThreads) lk_mean_center_int_kernel(const float2 *xy, const uint32_t *off, int n_sectors,
+                                                                          float2 *center) {
+  constexpr int WAVES = kMeanThreads / kWave;
+  __shared__ int lds_x[3 * WAVES], lds_y[3 * WAVES], lds_first[WAVES];
+  __shared__ long long lds_l[3];
+  const int sec = (int)blockIdx.x;
+  if (sec >= n_sectors)
+    return;
+  const uint32_t b = off[sec], e = off[sec + 1];
+  const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  long long sx = 0, sy = 0;
+  uint32_t k = b;
+  while (k < e) { // uniform over the workgroup
+    AxisPass ax, ay;
+    ax.begin(sx);
+    ay.begin(sy);
+    const uint32_t i0 = k + (uint32_t)tid * kMeanItems;
+    short x[kMeanItems], y[kMeanItems]; // (kept for the walk; coordinates are below 2^15 in any image this engine takes)
+    int n_mine = 0;
+#pragma unroll
+    for (int j = 0; j < kMeanItems; ++j) {
+      const uint32_t i = i0 + j;
+      x[j] = y[j] = 0;
+      if (i < e) {
+        const float2 q = xy[i];
+        x[j] = (short)(int)q.x;
+        y[j] = (short)(int)q.y;
+        ax.add((int)q.x);
+        ay.add((int)q.y);
+        ++n_mine;
+      }
+    }
+    __syncthreads(); // (the previous pass is done with lds)
+    ParityMap all_x, all_y;
+    const ParityMap ex = workgroup_prefix(ax.m, lds_x, all_x);
+    const ParityMap ey = workgroup_prefix(ay.m, lds_y, all_y);
+    const int gx_before = ax.p_start ? ex.g1 : ex.g0, px_mine = (ex.pn >> ax.p_start) & 1;
+    const int gy_before = ay.p_start ? ey.g1 : ey.g0, py_mine = (ey.pn >> ay.p_start) & 1;
+    const bool crosses = sx + ((long long)(gx_before + (px_mine ? ax.m.g1 : ax.m.g0)) << ax.sh) >= ax.limit ||
+                         sy + ((long long)(gy_before + (py_mine ? ay.m.g1 : ay.m.g0)) << ay.sh) >= ay.limit;
+    // the first run whose end leaves a binade, on either axis
+    const unsigned long long cb = __ballot(crosses);
+    if (lane == 0)
+      lds_first[wave] = cb ? wave * kWave + (int)__builtin_ctzll(cb) : kMeanThreads;
+    __syncthreads();
+    int first = kMeanThreads;
+    for (int w = 0; w < WAVES; ++w)
+      first = min(first, lds_first[w]);
+    if (first == kMeanThreads) { // the whole pass stays inside both binades
+      sx += (long long)(ax.p_start ? all_x.g1 : all_x.g0) << ax.sh;
+      sy += (long long)(ay.p_start ? all_y.g1 : all_y.g0) << ay.sh;
+      k += kMeanThreads * kMeanItems;
+      continue;
+    }
+    if (tid == first) { // my start is still inside both: walk to the first crossing with the exact rule
+      long long vx = sx + ((long long)gx_before << ax.sh), vy = sy + ((long long)gy_before << ay.sh);
+      int j = 0;
+      for (; j < n_mine; ++j) {
+        vx = rne24(vx + (long long)x[j]);
+        vy = rne24(vy + (long long)y[j]);
+        if (vx >= ax.limit || vy >= ay.limit) {
+          ++j;
+          break;
+        }
+      }
+      lds_l[0] = vx;
+      lds_l[1] = vy;
+      lds_l[2] = (long long)(i0 + (uint32_t)j);
+    }
+    __syncthreads();
+    sx = lds_l[0];
+    sy = lds_l[1];
+    k = (uint32_t)lds_l[2];
+  }
+  if (threadIdx.x == 0) {
+    const float n = (float)(e - b);
+    center[sec] = make_float2(__fdiv_rn((float)sx, n), __fdiv_rn((float)sy, n)); // (both sums are exact floats)
+  }
 }
 
 } // namespace
@@ -2812,6 +3095,39 @@ hipError_t lk_launch_decimate(const float2 *xy_prev, const uint32_t *off_prev, c
                      st, xy_prev, n_prev, 1.f / (float)mag, pos, tiles, xy_out);
   hipLaunchKernelGGL(lk_decimate_offsets_kernel, dim3((unsigned)(n_sectors + 256) / 256), dim3(256), 0, st, off_prev,
                      n_prev, pos, tiles, n_tiles, n_sectors, off_out);
+  return hipGetLastError();
+}
+
+static_assert(kLkRoiTile == kScanTile, "one ROI tile = one pass of the block scan");
+
+// pass 1: per-tile counts -> exclusive prefix in place (tiles[n_tiles] = total, also *n_out)
+hipError_t lk_launch_roi_count(const LkRoiSector *sectors, const LkRoiFlat *flats, const uint32_t *tile_begin, int n_sectors,
+                               uint32_t n_tiles, uint32_t *tiles, uint32_t *n_out, hipStream_t st) {
+  if (n_tiles == 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(lk_roi_tile_kernel<false>, dim3(n_tiles), dim3(kScanThreads), 0, st, sectors, flats, tile_begin, n_sectors,
+                     tiles, (const uint32_t *)nullptr, (float2 *)nullptr);
+  hipLaunchKernelGGL(lk_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, tiles, (int)n_tiles, n_out);
+  return hipGetLastError();
+}
+
+// pass 2: the samples and the per-sector offsets
+hipError_t lk_launch_roi_fill(const LkRoiSector *sectors, const LkRoiFlat *flats, const uint32_t *tile_begin, int n_sectors,
+                              uint32_t n_tiles, const uint32_t *tiles, float2 *xy, uint32_t *off, hipStream_t st) {
+  if (n_tiles == 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(lk_roi_tile_kernel<true>, dim3(n_tiles), dim3(kScanThreads), 0, st, sectors, flats, tile_begin, n_sectors,
+                     (uint32_t *)nullptr, tiles, xy);
+  hipLaunchKernelGGL(lk_roi_offsets_kernel, dim3((unsigned)(n_sectors + 256) / 256), dim3(256), 0, st, tile_begin, tiles, n_sectors,
+                     off);
+  return hipGetLastError();
+}
+
+// integer, non-negative sample lists (device-masked annular / blob sectors): the same mean, evaluated in parallel
+hipError_t lk_launch_mean_center_int(const float2 *xy, const uint32_t *off, int n_sectors, float2 *center, hipStream_t st) {
+  if (n_sectors <= 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(lk_mean_center_int_kernel, dim3((unsigned)n_sectors), dim3(kMeanThreads), 0, st, xy, off, n_sectors, center);
   return hipGetLastError();
 }
 

@@ -8,6 +8,7 @@
 //   blob         polygon_class.cpp:224-429 (ear clipping + per-triangle scan fill)
 // plus the per-level decimation and centres of pyramid_class.cpp:289-362.
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdint>
@@ -48,54 +49,75 @@ inline void rect_points(int x0, int y0, int x1, int y1, std::vector<float> &xy) 
     }
 }
 
-// manager_class.cpp:816-940
-inline bool annular_points(float r, float dr, float a, float da, float cx, float cy, int as,
-                           std::vector<float> &xy) {
+// manager_class.cpp:816-940.  The geometry of one annular sector as the scan uses it: bounding box
+// from the four corners (outer ones x 1.2, the reference's "cheap sag" margin) and the arc midpoint,
+// truncated to int (:862-895), squared radii, corners for the wedge test (:907-918).  Shared by the
+// host scan below and the device mask (lk_roi_tile_kernel) so that both test the same floats.
+struct AnnularGeometry {
+  int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+  float cx = 0, cy = 0, ri2 = 0, ro2 = 0, ro = 0; // (ro: outer radius - every kept sample is closer to the centre)
+  float q00x = 0, q01x = 0, q10x = 0, q11x = 0, q00y = 0, q01y = 0, q10y = 0, q11y = 0;
+  int as = 1;
+};
+inline bool annular_geometry(float r, float dr, float a, float da, float cx, float cy, int as, AnnularGeometry &g) {
   if (as <= 0)
     return false;
-  int x0, y0, x1, y1;
-  float q00x = 0, q01x = 0, q10x = 0, q11x = 0, q00y = 0, q01y = 0, q10y = 0, q11y = 0;
+  g = AnnularGeometry();
+  g.cx = cx, g.cy = cy, g.as = as;
   const float ro = r + dr;
   if (as == 1) {
-    x0 = (int)(cx - ro);
-    x1 = (int)(cx + ro);
-    y0 = (int)(cy - ro);
-    y1 = (int)(cy + ro);
+    g.x0 = (int)(cx - ro);
+    g.x1 = (int)(cx + ro);
+    g.y0 = (int)(cy - ro);
+    g.y1 = (int)(cy + ro);
   } else {
     float s0 = (float)std::sin((double)a), c0 = (float)std::cos((double)a);
     float s1 = (float)std::sin((double)(a + da)), c1 = (float)std::cos((double)(a + da));
     float s2 = (float)std::sin((double)(a + da / 2.f)), c2 = (float)std::cos((double)(a + da / 2.f));
-    q00x = cx + r * c0;
-    q01x = cx + r * c1;
-    q10x = cx + ro * c0 * 1.2f; // the reference's "cheap sag" margin
-    q11x = cx + ro * c1 * 1.2f;
-    q00y = cy + r * s0;
-    q01y = cy + r * s1;
-    q10y = cy + ro * s0 * 1.2f;
-    q11y = cy + ro * s1 * 1.2f;
+    g.q00x = cx + r * c0;
+    g.q01x = cx + r * c1;
+    g.q10x = cx + ro * c0 * 1.2f; // the reference's "cheap sag" margin
+    g.q11x = cx + ro * c1 * 1.2f;
+    g.q00y = cy + r * s0;
+    g.q01y = cy + r * s1;
+    g.q10y = cy + ro * s0 * 1.2f;
+    g.q11y = cy + ro * s1 * 1.2f;
     float ax = cx + ro * c2, ay = cy + ro * s2;
     auto mn = [](float u, float v) { return v < u ? v : u; };
     auto mx = [](float u, float v) { return u < v ? v : u; };
-    x0 = (int)mn(ax, mn(mn(q00x, q01x), mn(q10x, q11x)));
-    x1 = (int)mx(ax, mx(mx(q00x, q01x), mx(q10x, q11x)));
-    y0 = (int)mn(ay, mn(mn(q00y, q01y), mn(q10y, q11y)));
-    y1 = (int)mx(ay, mx(mx(q00y, q01y), mx(q10y, q11y)));
+    g.x0 = (int)mn(ax, mn(mn(g.q00x, g.q01x), mn(g.q10x, g.q11x)));
+    g.x1 = (int)mx(ax, mx(mx(g.q00x, g.q01x), mx(g.q10x, g.q11x)));
+    g.y0 = (int)mn(ay, mn(mn(g.q00y, g.q01y), mn(g.q10y, g.q11y)));
+    g.y1 = (int)mx(ay, mx(mx(g.q00y, g.q01y), mx(g.q10y, g.q11y)));
   }
-  const float ro2 = ro * ro, ri2 = r * r;
-  for (float fx = (float)x0; fx < x1; ++fx) {
-    for (int j = y0; j < y1; ++j) {
-      float ex = fx - cx, ey = j - cy;
+  g.ro = ro;
+  g.ro2 = ro * ro;
+  g.ri2 = r * r;
+  return true;
+}
+
+inline void annular_points(const AnnularGeometry &g, std::vector<float> &xy) {
+  for (float fx = (float)g.x0; fx < g.x1; ++fx) {
+    for (int j = g.y0; j < g.y1; ++j) {
+      float ex = fx - g.cx, ey = j - g.cy;
       float r2 = ex * ex + ey * ey;
-      if (r2 > ri2 && r2 < ro2) {
-        float w1 = (q11x - fx) * (q01y - q11y) - (q11y - j) * (q01x - q11x);
-        float w2 = (q00x - fx) * (q10y - q00y) - (q00y - j) * (q10x - q00x);
-        if (w1 * w2 > 0 || as == 1) {
+      if (r2 > g.ri2 && r2 < g.ro2) {
+        float w1 = (g.q11x - fx) * (g.q01y - g.q11y) - (g.q11y - j) * (g.q01x - g.q11x);
+        float w2 = (g.q00x - fx) * (g.q10y - g.q00y) - (g.q00y - j) * (g.q10x - g.q00x);
+        if (w1 * w2 > 0 || g.as == 1) {
           xy.push_back(fx);
           xy.push_back((float)j);
         }
       }
     }
   }
+}
+inline bool annular_points(float r, float dr, float a, float da, float cx, float cy, int as,
+                           std::vector<float> &xy) {
+  AnnularGeometry g;
+  if (!annular_geometry(r, dr, a, da, cx, cy, as, g))
+    return false;
+  annular_points(g, xy);
   return true;
 }
 
@@ -182,29 +204,41 @@ class BlobPolygon {
     icpt = xa - slope * ya;
     return true;
   }
-  // flat-sided triangle: (x1,y1) and (x2,y2) share y; polygon_class.cpp:349-403
-  static void fill_flat(float x1, float y1, float x2, float y2, float x3, float y3,
-                        std::vector<float> &xy) {
+public:
+  // one flat-sided half triangle as the scan fill walks it: rows j0 .. j1-1, pixels
+  // ceil(ls*j + li) .. ceil(rs*j + ri) - 1 of each (polygon_class.cpp:349-403)
+  struct Flat {
+    float ls = 0, li = 0, rs = 0, ri = 0;
+    int j0 = 0, j1 = 0;
+  };
+
+private:
+  // flat-sided triangle: (x1,y1) and (x2,y2) share y; false: nothing to fill (:356-361)
+  static bool flat_of(float x1, float y1, float x2, float y2, float x3, float y3, Flat &f) {
     int dy = (int)(std::floor((double)y3) - std::floor((double)y1));
     int dx = (int)(std::floor((double)x2) - std::floor((double)x1));
     if (dx == 0 || dy == 0)
-      return;
+      return false;
     float lx = dx > 0 ? x1 : x2, ly = dx > 0 ? y1 : y2;
     float rx = dx > 0 ? x2 : x1, ry = dx > 0 ? y2 : y1;
-    float ls = 0, li = 0, rs = 0, ri = 0;
-    edge_line(lx, ly, x3, y3, ls, li);
-    edge_line(rx, ry, x3, y3, rs, ri);
-    int j0 = dy > 0 ? (int)std::ceil((double)y1) : (int)std::ceil((double)y3);
-    int j1 = dy > 0 ? (int)std::ceil((double)y3) : (int)std::ceil((double)y1);
-    for (int j = j0; j < j1; ++j) {
-      int i0 = (int)std::ceil(ls * (float)j + li), i1 = (int)std::ceil(rs * (float)j + ri);
+    f = Flat();
+    edge_line(lx, ly, x3, y3, f.ls, f.li);
+    edge_line(rx, ry, x3, y3, f.rs, f.ri);
+    f.j0 = dy > 0 ? (int)std::ceil((double)y1) : (int)std::ceil((double)y3);
+    f.j1 = dy > 0 ? (int)std::ceil((double)y3) : (int)std::ceil((double)y1);
+    return f.j1 > f.j0;
+  }
+  static void fill_flat(const Flat &f, std::vector<float> &xy) {
+    for (int j = f.j0; j < f.j1; ++j) {
+      int i0 = (int)std::ceil(f.ls * (float)j + f.li), i1 = (int)std::ceil(f.rs * (float)j + f.ri);
       for (int i = i0; i < i1; ++i) {
         xy.push_back((float)i);
         xy.push_back((float)j);
       }
     }
   }
-  static void fill_triangle(const float *t, std::vector<float> &xy) { // :283-347
+  // the (at most two) half triangles of one triangle, in fill order (:283-347)
+  static int flats_of_triangle(const float *t, Flat out[2]) {
     const float x[3] = {t[0], t[2], t[4]}, y[3] = {t[1], t[3], t[5]};
     int hi, mid, lo;
     if (y[0] > y[1]) {
@@ -218,15 +252,24 @@ class BlobPolygon {
     }
     float slope, icpt;
     if (!edge_line(x[lo], y[lo], x[hi], y[hi], slope, icpt))
-      return;
+      return 0;
     float sy = y[mid], sx = slope * sy + icpt; // split point on the long edge
-    fill_flat(x[mid], y[mid], sx, sy, x[hi], y[hi], xy);
-    fill_flat(x[mid], y[mid], sx, sy, x[lo], y[lo], xy);
+    int n = 0;
+    if (flat_of(x[mid], y[mid], sx, sy, x[hi], y[hi], out[n]))
+      ++n;
+    if (flat_of(x[mid], y[mid], sx, sy, x[lo], y[lo], out[n]))
+      ++n;
+    return n;
   }
-
-public:
-  // returns false for a self-intersecting contour (error_bad_domain)
-  static bool inside_points(const float *contour, int nv, std::vector<float> &xy) {
+  static void fill_triangle(const float *t, std::vector<float> &xy) {
+    Flat f[2];
+    const int n = flats_of_triangle(t, f);
+    for (int k = 0; k < n; ++k)
+      fill_flat(f[k], xy);
+  }
+  // simple-polygon check, orientation, ear clipping: triangles (6 floats each) in clipping order;
+  // false for a self-intersecting or degenerate contour
+  static bool triangulate(const float *contour, int nv, std::vector<float> &tris) {
     if (nv < 3)
       return false;
     BlobPolygon P;
@@ -244,7 +287,6 @@ public:
       P.v_[w].ear = P.diagonal(P.v_[w].pv, P.v_[w].nx);
       w = P.v_[w].nx;
     } while (w != P.head_);
-    std::vector<float> tris;
     auto emit = [&](int a, int b, int c) {
       const int id[3] = {a, b, c};
       for (int k = 0; k < 3; ++k) {
@@ -274,6 +316,35 @@ public:
         return false; // degenerate input (the reference would not terminate)
     }
     emit(P.v_[P.head_].pv, P.head_, P.v_[P.head_].nx);
+    return true;
+  }
+
+public:
+  // the half triangles of the whole blob in fill order (what the device mask walks);
+  // false for a self-intersecting contour (error_bad_domain)
+  static bool flat_triangles(const float *contour, int nv, std::vector<Flat> &out) {
+    std::vector<float> tris;
+    if (!triangulate(contour, nv, tris))
+      return false;
+    for (size_t t = 0; t < tris.size() / 6; ++t) {
+      Flat f[2];
+      const int n = flats_of_triangle(&tris[6 * t], f);
+      out.insert(out.end(), f, f + n);
+    }
+    return true;
+  }
+
+  // the scan fill of those half triangles, in order (the host form of the device mask)
+  static void fill(const std::vector<Flat> &flats, std::vector<float> &xy) {
+    for (const Flat &f : flats)
+      fill_flat(f, xy);
+  }
+
+  // returns false for a self-intersecting contour (error_bad_domain)
+  static bool inside_points(const float *contour, int nv, std::vector<float> &xy) {
+    std::vector<float> tris;
+    if (!triangulate(contour, nv, tris))
+      return false;
     // Scan fill, triangle by triangle in clipping order.  Large blobs: the triangles are filled
     // by a few threads into lists of their own and joined in that order (same samples, same order).
     const size_t n_tri = tris.size() / 6;

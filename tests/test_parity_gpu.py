@@ -1587,3 +1587,66 @@ def test_random_mix_of_sectors(oracle, seed, model, interp):
         one, _ = e.correlate(int(s), np.zeros(6, np.float32))
         assert one.tobytes() == inv[s].tobytes(), s
     e.close()
+
+
+@pytest.mark.gpu
+def test_device_roi_masks_equal_the_host_scans(oracle, monkeypatch):
+    """Annular and blob sectors are rasterised by the device mask at commit (lk_roi_tile_kernel: the CPU
+    engine's predicates on the bounding box walked x outer / y inner, the blob's scan lines from the
+    host ear clipper, order-preserving compaction) - the counterpart of cudaPolygon's thrust
+    rasterise + remove_if (cuda_polygon.cuh:180-292).  Lists, centres, per-level counts and records
+    must equal the host scans' (LK_HOST_ROI=1) and the oracle's, bit for bit - also for the reference's
+    own polygonBlob_class outputs and for sectors mixed in one domain."""
+    und, dfm = ca.speckle.speckle_pair(768, 768, p=(0.9, 0.4, 0.001, 0.0005, -0.0005, 0.0015), seed=21)
+    g = np.load(os.path.join(GOLD, "ref_blob.npz"))
+    blobs = [n[:-len("_contour")] for n in g.files if n.endswith("_contour") and int(g[n[:-len("_contour")] + "_count"][0]) > 0]
+    assert len(blobs) >= 5
+    rs, as_ = 3, 5
+    dr, da = np.float32((330.0 - 90.0) / rs), np.float32(2 * np.pi) / np.float32(as_)
+    ann = [(np.float32(90.0 + i * dr), dr, np.float32(j) * da, da, 384.0, 380.0, as_) for i in range(rs) for j in range(as_)]
+    ann.append((30.0, 55.0, 0.0, np.float32(2 * np.pi), 384.0, 384.0, 1))     # a full ring
+
+    def build(host):
+        monkeypatch.setenv("LK_HOST_ROI", "1" if host else "0")
+        e = ca.HipCorrelationEngine(py_stop=3)
+        e.set_batch_invariant(True)
+        e.set_undeformed_image(und)
+        e.set_deformed_image(dfm)
+        s = 0
+        for q in ann[:7]:
+            e.resetPolygon_annular(s, *q)
+            s += 1
+        e.set_sectors_annular(s, np.float32([q[:6] for q in ann[7:-1]]), as_)
+        s += len(ann) - 8
+        e.resetPolygon_annular(s, *ann[-1])
+        s += 1
+        for name in blobs:
+            c = g[f"{name}_contour"].astype(np.float32)
+            c = (c - c.mean(0)) * np.float32(200.0 / np.abs(c - c.mean(0)).max()) + np.float32([384.0, 384.0])   # inside the image
+            e.resetPolygon_blob(s, c)
+            s += 1
+        before = e.getUndXY0ToCPU(2).tobytes()           # a list asked for BEFORE the commit: the host scan on demand
+        e.commit_sectors()
+        S = e.n_sectors
+        out = ([e.getUndXY0ToCPU(k).tobytes() for k in range(S)], [e.sector_info(k) for k in range(S)],
+               [[e.sector_level_count(k, l) for l in range(4)] for k in range(S)], e.correlate_all(np.zeros(6, np.float32)).tobytes())
+        assert out[0][2] == before
+        e.close()
+        return out
+
+    dev, host = build(False), build(True)
+    for i, (a, b) in enumerate(zip(dev, host)):
+        assert a == b, i
+    # ... and the oracle's lists for the annular sectors
+    for k, q in enumerate(ann):
+        want = oracle.annular_points(*q)
+        assert np.frombuffer(dev[0][k], np.float32).reshape(-1, 2).tobytes() == want.tobytes(), k
+    assert min(n for n, _, _ in dev[1]) > 500
+    # the reference's own scan-fill outputs, through the device mask
+    e = ca.HipCorrelationEngine()
+    for name in blobs:
+        e.clear_sectors()
+        e.resetPolygon_blob(0, g[f"{name}_contour"])
+        e.commit_sectors()
+        assert np.array_equal(e.getUndXY0ToCPU(0), g[f"{name}_pts"].astype(np.float32)), name
+    e.close()
