@@ -84,12 +84,14 @@ def speckle_pair(h, w, p=(1.3, -0.7, 0.002, 0.0, 0.0, -0.001), seed=7, sigma=2.5
     return und, dfm
 
 
-def speckle_sequence(h, w, n_frames, velocity=(0.8, -0.4), dilation=1e-4, seed=7, sigma=2.5):
-    """Frames 0..n_frames-1 with constant-velocity translation and dilation (config C4)."""
+def speckle_sequence(h, w, n_frames, velocity=(0.8, -0.4), dilation=1e-4, seed=7, sigma=2.5, device=None):
+    """Frames 0..n_frames-1 with constant-velocity translation and dilation (config C4).
+    device="cuda" renders with torch on the GPU (the 64-frame 2048^2 sequence)."""
     xs, ys, amps = blobs(h, w, seed)
     frames = []
     for f in range(n_frames):
         p = (velocity[0] * f, velocity[1] * f, dilation * f, 0.0, 0.0, dilation * f)
         xd, yd = deform(xs, ys, h, w, p)
-        frames.append(_render(h, w, xd, yd, amps, sigma))
+        frames.append(_render_torch(h, w, xd, yd, amps, sigma, device) if device is not None
+                      else _render(h, w, xd, yd, amps, sigma))
     return frames
