@@ -121,7 +121,7 @@ def test_config4_sequence_of_64_frames(monkeypatch):
     assert col is not None
     for k in (0, 1, 31, 62):
         u_k = np.array([float(r.split(",")[col]) for r in rows[k * S:(k + 1) * S:97]])
-        assert abs(np.nanmedian(u_k) - 0.8 * (k + 1)) < 0.08, k
+        assert abs(np.nanmedian(u_k) - 0.8 * (k + 1)) < 0.08 + 0.005 * (k + 1), k   # (a sparse sample of the rows; the dilation spreads u by +-1e-4 k x)
     # the one-pair-at-a-time loop gives the same report and frame_results, bit for bit
     text_sync, res_sync = run(True)
     assert text_sync == text and res_sync.tobytes() == res.tobytes()
