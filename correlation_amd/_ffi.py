@@ -98,6 +98,7 @@ SYMBOLS = {
     "lk_sample": (C.c_int, [_P, C.c_int, C.c_int, _F, C.c_int, _F]),
     "lk_damped_solve": (C.c_int, [_P, C.c_int, _F, _F, C.c_float, C.c_float, C.c_int, _F]),
     "lk_get_stats": (C.c_int, [_P, C.POINTER(LkStats)]),
+    "lk_get_sector_stats": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     # include/lk_tracker.h
     "lk_tracker_create": (C.c_int, [_P, C.POINTER(_P)]),
     "lk_tracker_destroy": (None, [_P]),

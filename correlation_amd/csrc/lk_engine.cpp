@@ -2302,4 +2302,15 @@ int lk_get_stats(lk_engine *e, lk_stats *out) {
   return LK_ERROR_NONE;
 }
 
+int lk_get_sector_stats(lk_engine *e, uint32_t *out) {
+  if (!e || !out)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!e->committed)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_sector_stats: no committed sectors");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(out, e->d_stats.p, 4 * (size_t)e->S * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return LK_ERROR_NONE;
+}
+
 } // extern "C"

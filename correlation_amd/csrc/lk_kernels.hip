@@ -677,7 +677,8 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
 template <int GROUP> constexpr int ord_stride() { return GROUP + 4; } // +4: the 128-bit reads of neighbouring lanes hit different banks
 template <int N, int GROUP> constexpr int ord_floats() { return (kWave / GROUP) * N * ord_stride<GROUP>(); }
 
-template <int MODEL, int INTERP, int GROUP>
+// CHUNKED: number_of_threads > 1 (the chunk boundaries cost a test per addition; T = 1 has none)
+template <int MODEL, int INTERP, int GROUP, bool CHUNKED>
 __device__ __forceinline__ bool evaluate_ordered(const LevelCtx &c, const float (&p)[6],
                                                  Sums<n_params(MODEL)> &S, float *ord, int threads) {
   static_assert(GROUP == 16 || GROUP == 64, "one 16-lane row or one wavefront per sector");
@@ -690,7 +691,7 @@ __device__ __forceinline__ bool evaluate_ordered(const LevelCtx &c, const float 
   const int v0 = g < N ? g : 0, v1 = (TWO && g + 16 < N) ? g + 16 : 0; // (idle lanes shadow sum 0)
   float acc0 = 0.f, acc1 = 0.f, tot0 = 0.f, tot1 = 0.f;
   // thread chunks of the reference: chunk t has n/T + (t < n%T) samples
-  const int T = threads < 1 ? 1 : threads;
+  const int T = CHUNKED ? (threads < 1 ? 1 : threads) : 1;
   const int cq = c.n / T, cr = c.n - cq * T;
   int t_idx = 0, next_b = cq + (cr > 0 ? 1 : 0);
   bool bad = false;
@@ -706,15 +707,13 @@ __device__ __forceinline__ bool evaluate_ordered(const LevelCtx &c, const float 
     if (k < c.n) {
       f32x2 q;
       if (c.rw > 0) { // x outer, y inner: k -> (column, row) of the rectangle
-        int col = (int)((float)k * inv_rh); // within a few units of k / rh; corrected below
+        int col = (int)((float)k * inv_rh); // k / rh to within one unit below 2^23 samples, two below 2^25
         int row = k - col * rh;
-        while (row < 0) {
-          row += rh;
-          --col;
-        }
-        while (row >= rh) {
-          row -= rh;
-          ++col;
+#pragma unroll
+        for (int fix = 0; fix < 2; ++fix) {
+          const int lo = row < 0 ? 1 : 0, hi = row >= rh ? 1 : 0;
+          row += (lo - hi) * rh;
+          col += hi - lo;
         }
         q.x = (float)(c.rx + col);
         q.y = (float)(c.ry + row);
@@ -764,7 +763,7 @@ __device__ __forceinline__ bool evaluate_ordered(const LevelCtx &c, const float 
       const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (T > 1 && base + 4 * j4 + j == next_b) { // a thread chunk ends before this sample (:253-275)
+        if (CHUNKED && base + 4 * j4 + j == next_b) { // a thread chunk ends before this sample (:253-275)
           tot0 += acc0;
           acc0 = 0.f;
           if constexpr (TWO) {
@@ -1567,9 +1566,15 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
   };
 
 #ifdef LK_TRACE
+#ifndef LK_TRACE_PICK // which instance leaves the trace, e.g. -D'LK_TRACE_PICK(G,S)=(G==1)'
+#define LK_TRACE_PICK(G, S) ((G) > 1 && !(S))
+#endif
+#ifndef LK_TRACE_WHEN // ... and which of its launches, e.g. -D'LK_TRACE_WHEN(a)=((a).finisher!=0)'
+#define LK_TRACE_WHEN(a) true
+#endif
   const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz, one clock for the whole device
   const unsigned long long tr_c0 = __builtin_amdgcn_s_memtime();
-  unsigned long long tr_eval = 0, tr_steps = 0;
+  unsigned long long tr_eval = 0, tr_steps = 0, tr_solve = 0, tr_fetch = 0, tr_post = 0;
 #endif
   for (;;) {
     bool may_fetch = true;
@@ -1586,6 +1591,9 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
         cold_slot = cold_lds + ((int)threadIdx.x / GROUP) * kColdWords;
       }
     }
+#ifdef LK_TRACE_FINE
+    const unsigned long long tr_f0 = __builtin_amdgcn_s_memtime();
+#endif
     if (phase == PH_FETCH && may_fetch) { // take the next sector
       int slot = 0;
       // (lists of parked sectors: their length is read BEFORE the ticket is drawn - see the rewind below)
@@ -1672,6 +1680,9 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
         phase = PH_EXIT;
       }
     }
+#ifdef LK_TRACE_FINE
+    tr_fetch += __builtin_amdgcn_s_memtime() - tr_f0;
+#endif
     bool active = phase < PH_FETCH;
     if constexpr (GROUP >= kWave) {
       if (!active)
@@ -1785,15 +1796,18 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
 #endif
     bool err;
     if constexpr (ORD) {
-      err = ordered_all ? evaluate_ordered<MODEL, INTERP, GROUP>(ce, p, S, ord_lds, a.reference_order)
-                        : evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds, &team, wide, finisher,
-                                                                  GROUP == 16 ? width : 0);
+      err = !ordered_all ? evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds, &team, wide, finisher, GROUP == 16 ? width : 0)
+            : a.reference_order > 1 ? evaluate_ordered<MODEL, INTERP, GROUP, true>(ce, p, S, ord_lds, a.reference_order)
+                                    : evaluate_ordered<MODEL, INTERP, GROUP, false>(ce, p, S, ord_lds, 1);
     } else {
       err = evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds, &team, wide, finisher, GROUP == 16 ? width : 0);
     }
 #ifdef LK_TRACE
     tr_eval += __builtin_amdgcn_s_memtime() - tr_e0;
     ++tr_steps;
+#endif
+#ifdef LK_TRACE_FINE
+    const unsigned long long tr_p0 = __builtin_amdgcn_s_memtime(); // (tr_post includes the solve)
 #endif
     if constexpr (GROUP == 512) {
       // A team whose workgroups did not all show up (a workgroup not resident for ~1 s: foreign
@@ -1838,7 +1852,13 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
           tent[i] = p[i];
         // (SAFE kernels up to one wavefront per sector: every lane of a 16-lane row holds the same system - the QR
         // runs spread over the row)
+#ifdef LK_TRACE
+        const unsigned long long tr_s0 = __builtin_amdgcn_s_memtime();
+#endif
         const bool wc = damped_step<P, SAFE || STARVED>(S, lam_use, c.scaling, p, starved, nullptr, SAFE && GROUP >= 16 && GROUP <= kWave); // p += dp
+#ifdef LK_TRACE
+        tr_solve += __builtin_amdgcn_s_memtime() - tr_s0;
+#endif
         if (!wc && !starved)
           ++k.n_ill;
         bool ill_parked = false;
@@ -1927,10 +1947,13 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
       else
         cold.store(cold_slot, k);
     }
+#ifdef LK_TRACE_FINE
+    tr_post += __builtin_amdgcn_s_memtime() - tr_p0;
+#endif
   }
 #ifdef LK_TRACE
-  if constexpr (GROUP > 1 && !SAFE) {
-    if (((int)threadIdx.x & 63) == 0 && blockIdx.x < 16384u) {
+  if constexpr (LK_TRACE_PICK(GROUP, SAFE)) {
+    if (((int)threadIdx.x & 63) == 0 && blockIdx.x < 16384u && LK_TRACE_WHEN(a)) {
       unsigned long long *w = g_lk_trace + 8 * ((size_t)blockIdx.x);
       unsigned hw, xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -1938,11 +1961,16 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
       w[0] = tr_t0;
       w[1] = __builtin_amdgcn_s_memrealtime();
       w[2] = tr_eval;
-      w[3] = tr_steps;
+      w[3] = tr_steps | ((unsigned long long)gridDim.x << 32);
+#ifdef LK_TRACE_FINE // (instead of the placement: cycles of the fetch block and of everything after the evaluation)
+      w[4] = tr_fetch;
+      w[5] = tr_post;
+#else
       w[4] = hw;
       w[5] = xcc;
+#endif
       w[6] = __builtin_amdgcn_s_memtime() - tr_c0; // shader cycles of the whole wavefront
-      w[7] = gridDim.x;
+      w[7] = tr_solve; // cycles inside damped_step
     }
   }
 #endif
@@ -1988,7 +2016,8 @@ __global__ void __launch_bounds__(256) lk_eval_kernel(LkEvalArgs a) {
   if (a.ref_threads > 0) {
     if (OG == 16 && (int)threadIdx.x >= 16)
       c.n = 0;
-    err = evaluate_ordered<MODEL, INTERP, OG>(c, p, S, ord_lds, a.ref_threads);
+    err = a.ref_threads > 1 ? evaluate_ordered<MODEL, INTERP, OG, true>(c, p, S, ord_lds, a.ref_threads)
+                            : evaluate_ordered<MODEL, INTERP, OG, false>(c, p, S, ord_lds, 1);
   } else {
     err = evaluate<MODEL, INTERP, GROUP, 256>(c, p, S, lds);
   }

@@ -291,3 +291,9 @@ class HipCorrelationEngine:
         s = LkStats()
         self._chk(self.lib.lk_get_stats(self._h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in LkStats._fields_}
+
+    def sector_stats(self):
+        """[S][4] uint32 of the last solve: evaluations, sample evaluations, point iterations, ill-conditioned solves."""
+        out = np.zeros((self.n_sectors, 4), np.uint32)
+        self._chk(self.lib.lk_get_sector_stats(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out

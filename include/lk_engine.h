@@ -286,6 +286,9 @@ int lk_damped_solve(lk_engine *e, int n, const float *A_rowmajor_upper, const fl
                     float lambda, float scaling, int reference_solver, float *dp);
 
 int lk_get_stats(lk_engine *e, lk_stats *out);
+/* the same counters per sector of the last solve, registration order:
+ * out[s] = {evaluations, sample evaluations, point iterations, ill-conditioned solves} */
+int lk_get_sector_stats(lk_engine *e, uint32_t *out_4_per_sector);
 
 #ifdef __cplusplus
 }

@@ -8,19 +8,21 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import correlation_amd as ca  # noqa: E402
-from correlation_amd.workload import C2, C4, C4B  # noqa: E402
+from correlation_amd.workload import C2, C4, C4B, C5  # noqa: E402
 
-wl = {"C2": C2, "C4": C4, "C4B": C4B}[sys.argv[1] if len(sys.argv) > 1 else "C2"]
+wl = {"C2": C2, "C4": C4, "C4B": C4B, "C5": C5}[sys.argv[1] if len(sys.argv) > 1 else "C2"]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 cache = f"/tmp/speckle_{wl.size}.npz"
 if os.path.exists(cache):
     z = np.load(cache)
     und, dfm = z["und"], z["dfm"]
 else:
-    und, dfm = ca.speckle.speckle_pair(wl.size, wl.size, p=wl.truth, seed=7)
+    und, dfm = ca.speckle.speckle_pair(wl.size, wl.size, p=wl.truth if wl.size <= 2048 else (1.3, -0.7, 0.0005, 0.0, 0.0, -0.00025),
+                                       seed=7 if wl.size <= 2048 else 13, device="cuda" if wl.size > 2048 else None)
     np.savez(cache, und=und, dfm=dfm)
 e = ca.HipCorrelationEngine(fitting_model=wl.model, py_stop=wl.py_stop,
                             interpolation=int(os.environ.get("LK_INTERP", ca.IM_BICUBIC)))
+e.set_reference_order(int(os.environ.get("LK_REF_ORDER", 0)))   # tuning: the reference-order mode's time
 e.set_undeformed_image(und)
 e.set_deformed_image(dfm)
 grid = int(os.environ.get("LK_GRID", 0))   # tuning: another number of sectors of the same size

@@ -9,7 +9,9 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import correlation_amd as ca  # noqa: E402
-from correlation_amd.workload import C2 as wl  # noqa: E402
+from correlation_amd import workload  # noqa: E402
+
+wl = getattr(workload, os.environ.get("LK_TRACE_CONFIG", "C2"))   # (C4 with -D'LK_TRACE_PICK(G,S)=(G==1)': the one-lane kernel)
 
 und, dfm = ca.speckle.speckle_pair(wl.size, wl.size, p=wl.truth, seed=7)
 e = ca.HipCorrelationEngine(fitting_model=wl.model, py_stop=wl.py_stop)
@@ -25,7 +27,8 @@ lib = C.CDLL(ca.LIB_PATH)
 buf = np.zeros(8 * 16384, np.uint64)
 assert lib.lk_debug_trace(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
 t = buf.reshape(-1, 8)
-n = int(t[0, 7])
-t = t[:n]
+n = int(t[0, 3] >> 32)
+t = t[:n].copy()
+t[:, 3] &= 0xFFFFFFFF   # (steps; the upper half carried the grid size)
 np.savez_compressed(sys.argv[1] if len(sys.argv) > 1 else "/tmp/trace.npz", trace=t, solve_ms=st["solve_ms"])
 print("saved; analyse with scripts/trace_report.py")

@@ -531,6 +531,10 @@ def test_grid_10x10_affine_bicubic(oracle, speckle512):
     st = e.stats()
     assert st["sectors"] == 100 and st["evaluations"] > 300 and st["point_iterations"] >= 600
     assert st["algorithmic_bytes"] == 25 * st["sample_evaluations"] + 196 * st["evaluations"]
+    per = e.sector_stats()            # the same counters per sector (lk_get_sector_stats)
+    assert per.shape == (100, 4) and per[:, 0].sum() == st["evaluations"] and per[:, 1].sum() == st["sample_evaluations"]
+    assert per[:, 2].sum() == st["point_iterations"] and (per[:, 0] >= 3).all()   # at least one evaluation per level
+    assert (per[:, 1] >= per[:, 0]).all() and per[:, 3].sum() == st["ill_conditioned_solves"]
     # single-sector entry point == batch, bit for bit
     for s in (3, 58):
         one, _ = e.correlate(s, np.zeros(6, np.float32))
