@@ -1,26 +1,23 @@
 #!/bin/bash
 # Collects the evidence kept under profiles/ on the GPU box (run through gpurun from the repo root):
-#   scripts/profile_round.sh r01
-# 1. bench.py under rocprofv3 --kernel-trace --stats -> <tag>_bench.json, <tag>_bench_kernel_stats.csv
-# 2. separate --pmc passes on scripts/quick_solve.py (HBM traffic, L2, SQ activity) -> <tag>_pmc_summary.txt
+#   scripts/profile_round.sh r02
+# 1. bench.py (default command: one pair at a time) under rocprofv3 --kernel-trace --stats
+#    -> <tag>_bench.json, <tag>_bench_kernel_stats.csv
+# 2. separate --pmc passes on scripts/quick_solve.py (HBM traffic, L2, SQ activity) -> <tag>_pmc_summary.txt,
+#    <tag>_traffic.json (the per-launch HBM bytes bench.py quotes as roofline.traffic)
+# 3. config 4's launch chain (start / end of every launch of one solve) -> <tag>_c4_chain.txt
+# 4. if build/tune/liblk_trace.so exists (scripts/tune_build.sh trace -DLK_TRACE): the per-wavefront timeline of
+#    one C2 launch -> <tag>_wave_timeline.txt
 # PMC passes never share a run with tracing (pool rule) and the program follows `--` directly.
 set -uo pipefail
-tag=${1:-r01}
+tag=${1:-r02}
 out=gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-# The default command keeps 3 pairs in flight on 16-lane-group engines and measures the single launch
-# on a 32-lane-group engine: the two template instances show up as separate rows of the stats, and the
-# row of the 32-lane instance (launched one at a time only) is what roofline.kernel_ms has to agree with.
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o bench -- python3 bench.py --steps 100 --warmup 10 > "$out/${tag}_bench.json" 2> "$out/bench.err"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o bench -- python3 bench.py --steps 100 --warmup 10 > "$out/${tag}_bench.json" 2> "$out/bench.err"
 find "$out/trace" -name '*kernel_stats.csv' -exec cp {} "$out/${tag}_bench_kernel_stats.csv" \;
 find "$out/trace" -name '*kernel_trace.csv' -delete   # tens of MB; the stats are what is kept
 echo "bench traced" >> "$out/progress.log"
-# one pair at a time throughout (the 'sequential' block of the default output as its own run)
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace1" -o bench -- python3 bench.py --inflight 1 --steps 100 --warmup 10 --no-cpu-baseline --no-other-configs > "$out/${tag}_bench_inflight1.json" 2> "$out/bench1.err"
-find "$out/trace1" -name '*kernel_stats.csv' -exec cp {} "$out/${tag}_bench_inflight1_kernel_stats.csv" \;
-find "$out/trace1" -name '*kernel_trace.csv' -delete
-echo "bench --inflight 1 traced" >> "$out/progress.log"
 # derived counters take a whole pass each on gfx950 ("exceeds the capabilities of the hardware" otherwise)
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum" "SQ_INSTS_VALU SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"; do
@@ -29,5 +26,23 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_s
   echo "pass $i done" >> "$out/progress.log"
 done
 python3 scripts/summarize_pmc.py "$out" "$tag" > "$out/${tag}_pmc_summary.txt"
-tail -1 "$out/${tag}_bench.json" | cut -c1-300
+python3 - "$out/${tag}_pmc_summary.txt" "$tag" > "$out/${tag}_traffic.json" <<'PY'
+import json, re, sys
+kib = {}
+for line in open(sys.argv[1]):
+    m = re.match(r"lk_solve_kernel<3,\s*2,\s*32,\s*64,\s*false>\s+(FETCH_SIZE|WRITE_SIZE)\s+dispatches=\d+ mean=([0-9.e+]+)", line)
+    if m:
+        kib[m.group(1)] = float(m.group(2))
+print(json.dumps({"solve_kernel_hbm_bytes_per_launch_C2": (kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024.0,
+                  "source": f"profiles/{sys.argv[2]}_pmc_summary.txt (FETCH_SIZE + WRITE_SIZE of lk_solve_kernel<3,2,32,64,false>, KiB per dispatch; "
+                            "these byte / dword loads read 1:1 on the counter, calibrated on the pyramid kernel in profiles/r01_pmc_traffic.txt)"}, indent=1))
+PY
+timeout -k 10 200 rocprofv3 --kernel-trace -d "$out/c4" -o t -- python3 scripts/quick_solve.py C4 10 > "$out/c4.log" 2>&1
+{ grep solve_ms "$out/c4.log"; python3 scripts/c4_chain_timeline.py "$out/c4/t_results.db" 8; } > "$out/${tag}_c4_chain.txt" 2>&1
+if [ -f build/tune/liblk_trace.so ]; then
+  LK_ENGINE_LIB=build/tune/liblk_trace.so timeout -k 10 120 python3 scripts/trace_solve.py "$out/trace_c2.npz" > /dev/null 2>&1 &&
+    { python3 scripts/trace_brief.py "$out/trace_c2.npz"; python3 scripts/trace_report.py "$out/trace_c2.npz"; } > "$out/${tag}_wave_timeline.txt" 2>&1
+fi
+rm -rf "$out/c4" "$out"/pmc*/ "$out/trace"
+tail -1 "$out/${tag}_bench.json" | cut -c1-400
 cat "$out/${tag}_pmc_summary.txt"
