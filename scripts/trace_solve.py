@@ -17,7 +17,12 @@ und, dfm = ca.speckle.speckle_pair(wl.size, wl.size, p=wl.truth, seed=7)
 e = ca.HipCorrelationEngine(fitting_model=wl.model, py_stop=wl.py_stop)
 e.set_undeformed_image(und)
 e.set_deformed_image(dfm)
-e.set_rect_grid(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, wl.hs, wl.vs)
+grid = int(os.environ.get("LK_GRID", 0))   # another number of sectors of the same size (e.g. 32: wavefronts alone on their SIMDs)
+if grid:
+    pitch = (wl.x_end - wl.x_begin + 1) / wl.hs
+    e.set_rect_grid(wl.x_begin, wl.x_begin, wl.x_begin + grid * pitch - 1, wl.x_begin + grid * pitch - 1, grid, grid)
+else:
+    e.set_rect_grid(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, wl.hs, wl.vs)
 e.commit_sectors()
 g = np.zeros(6, np.float32)
 for _ in range(3):

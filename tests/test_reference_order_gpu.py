@@ -125,6 +125,34 @@ def test_config2_sectors_are_bit_identical(oracle, threads):
     e.close()
 
 
+def test_default_mode_stays_within_its_stated_bounds_on_config2(oracle):
+    """The DEFAULT mode (lane-parallel sums, root-free Cholesky) against the same oracle records, as absolute numbers
+    rather than yardsticks.  Measured on all 10 000 C2 sectors (bench.py, parity_vs_cpu.fast_mode): max |dp0,1|
+    1.5e-4 px, max relative chi difference 1.1e-3, same iteration count on 99.7 % of the sectors - the size of the
+    reference's own number_of_threads noise.  Asserted here with a factor ~3 of margin."""
+    w = wl.C2
+    pair = ca.speckle.speckle_pair(w.size, w.size, p=w.truth, seed=7)
+    e, o = engine_and_oracle(oracle, pair, threads=1, py_stop=w.py_stop)
+    e.set_reference_order(0)                                                            # the default mode
+    first, count = 4200, 1000
+    e.set_rect_grid(w.x_begin, w.x_begin, w.x_end, w.x_end, w.hs, w.vs, first, count)
+    e.commit_sectors()
+    got = e.correlate_all(np.zeros(6, np.float32))
+    lists, cen = grid_lists(oracle, w, first, count)
+    want = o.correlate_sectors(lists, centers=cen)
+    assert np.array_equal(got["error_code"], want["error_code"]) and np.array_equal(got["n_points"], want["n_points"])
+    assert np.array_equal(got["und_cx"], want["und_cx"]) and np.array_equal(got["und_cy"], want["und_cy"])
+    assert np.abs(got["p"][:, :2] - want["p"][:, :2]).max() < 5e-4                      # pixels
+    assert np.abs(got["p"][:, 2:] - want["p"][:, 2:]).max() < 5e-5                      # displacement gradients (measured 1.4e-5 = 1.3e-4 px over a sector's half width)
+    assert (np.abs(got["chi"] - want["chi"]) / want["chi"]).max() < 3e-3
+    assert (got["iterations"] == want["iterations"]).mean() >= 0.99
+    assert np.abs(got["iterations"] - want["iterations"]).max() <= 2
+    # ... while the reference-order mode on the very same engine gives the oracle's bytes
+    e.set_reference_order(1)
+    assert_same_bytes(e.correlate_all(np.zeros(6, np.float32)), want, "C2 after switching to reference order")
+    e.close()
+
+
 def test_switching_modes_on_a_committed_engine(oracle, speckle512):
     """lk_set_reference_order may come after lk_commit_sectors and may be switched off again."""
     e, o = engine_and_oracle(oracle, speckle512, threads=0)
