@@ -51,7 +51,9 @@ hipError_t lk_launch_roi_fill(const LkRoiSector *sectors, const LkRoiFlat *flats
                               uint32_t n_tiles, const uint32_t *tiles, float2 *xy, uint32_t *off, hipStream_t st);
 hipError_t lk_launch_stale_iterations(lk_result *r, int n, const int *carry_in, int *carry_out, hipStream_t st);
 hipError_t lk_launch_mean_center(const float2 *xy, const uint32_t *off, int n_sectors, float2 *center, hipStream_t st);
-hipError_t lk_launch_mean_center_int(const float2 *xy, const uint32_t *off, int n_sectors, float2 *center, hipStream_t st);
+size_t lk_mean_center_int_scratch_bytes(uint32_t n_samples, int n_sectors);
+hipError_t lk_launch_mean_center_int(const float2 *xy, const uint32_t *off, uint32_t n_samples, int n_sectors, void *scratch,
+                                     float2 *center, hipStream_t st);
 
 namespace {
 
@@ -240,6 +242,7 @@ struct lk_engine {
   DevBuf<LkHandoff> d_handoff;
   DevBuf<uint32_t> d_mid, d_finish_list, d_finish_count; // stragglers of the starved-level kernel
   DevBuf<uint32_t> d_ill_list, d_ill_count;              // sectors whose damped system met a bad pivot
+  DevBuf<uint32_t> d_mean_scratch;                       // chunk table / sums / maps of lk_mean_center_int_kernel
   int eval_cap = 32; // evaluations a lane of the starved-level kernel spends on one sector (0: no cap)
   int team_w = 0; // workgroups per sector of the team class
   int team_min_samples = 0; // per-sector team sizing (0: every team has team_w workgroups)
@@ -352,6 +355,7 @@ void lk_destroy(lk_engine *e) {
   e->d_finish_count.release();
   e->d_ill_list.release();
   e->d_ill_count.release();
+  e->d_mean_scratch.release();
   e->d_scratch.release();
   e->d_stale.release();
   e->d_warp.release();
@@ -1001,8 +1005,10 @@ static int build_lists_roi_device(lk_engine *e, const std::vector<int> &levels) 
   e->h_center.resize(2 * (size_t)S);
   // (the mask's coordinates are integers; non-negative ones - the ROI lies in the image - let the
   // chain be evaluated in parallel, see lk_mean_center_int_kernel)
-  if (non_negative)
-    HIPCHK(lk_launch_mean_center_int(e->d_xy[0].p, e->d_off[0].p, S, e->d_center.p, st));
+  if (non_negative) {
+    HIPCHK(e->d_mean_scratch.ensure((lk_mean_center_int_scratch_bytes(total, S) + 3) / 4));
+    HIPCHK(lk_launch_mean_center_int(e->d_xy[0].p, e->d_off[0].p, total, S, e->d_mean_scratch.p, e->d_center.p, st));
+  }
   else
     HIPCHK(lk_launch_mean_center(e->d_xy[0].p, e->d_off[0].p, S, e->d_center.p, st));
   HIPCHK(hipMemcpyAsync(e->h_center.data(), e->d_center.p, 2 * (size_t)S * sizeof(float), hipMemcpyDeviceToHost, st));

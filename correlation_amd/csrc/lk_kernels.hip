@@ -2709,10 +2709,11 @@ struct AxisPass { // one axis of one pass
   }
 };
 
-// exclusive composition prefix of `m` over the workgroup's threads; `all` = everybody's composition
+// exclusive composition prefix of `m` over the workgroup's THREADS threads; `all` = everybody's composition
+template <int THREADS = kMeanThreads>
 __device__ __forceinline__ ParityMap workgroup_prefix(const ParityMap &m, int *lds3, ParityMap &all) {
   const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  constexpr int WAVES = kMeanThreads / kWave;
+  constexpr int WAVES = THREADS / kWave;
   ParityMap inc = m;
 #pragma unroll
   for (int d = 1; d < kWave; d <<= 1) {
@@ -2744,79 +2745,278 @@ __device__ __forceinline__ ParityMap workgroup_prefix(const ParityMap &m, int *l
   return lane == 0 ? before : compose(before, o);
 }
 
+// A 4.2 M-sample list on ONE workgroup is 129 passes of 32 768 samples through one CU (4.4 ms).  The passes are
+// independent except for the state they hand on - the running sum, which a pass needs for its binade (the ulp)
+// and its parity.  The parity is what the maps are for; the binade can be PREDICTED: the float chain never strays
+// far from the exact integer prefix sum, so away from the powers of two the binade of the exact sum is the
+// binade of the chain.  Hence three launches:
+//   lk_mean_chunk_sums_kernel   exact integer sums of every chunk of 8192 samples (all chunks of all sectors at once);
+//   lk_mean_chunk_maps_kernel   per chunk and axis: the binade of the exact prefix sum at its start; if the exact
+//                               sum is still in that binade at its end, the chunk's parity map for that ulp;
+//   lk_mean_center_int_kernel   one workgroup per sector walks its chunks in order with the TRUE chain value: a map
+//                               applies iff the value is in the map's binade and stays there (checked, not
+//                               assumed) - one table lookup per chunk; any other chunk (a crossing inside, a
+//                               prediction off by the chain's drift) is walked by the exact passes above.
+// Nothing depends on the prediction being right; it only decides how many chunks take the slow path (C3's blob:
+// ~20 of 517).
+constexpr int kChunkThreads = 256, kChunkSamples = kChunkThreads * kMeanItems; // 8192 samples per chunk
+
+struct MeanChunk {
+  int gx0, gx1, pnx, shx; // shx < 0: no map (the exact sum leaves the binade inside the chunk)
+  int gy0, gy1, pny, shy;
+};
+
+// chunk_begin[s] = number of chunks of the sectors before s (one workgroup)
+__global__ void __launch_bounds__(1024) lk_mean_chunk_table_kernel(const uint32_t *off, int n_sectors, uint32_t *chunk_begin) {
+  __shared__ uint32_t lds[1024 / kWave];
+  uint32_t carry = 0;
+  for (int base = 0; base < n_sectors; base += 1024) {
+    const int sct = base + (int)threadIdx.x;
+    const uint32_t v = sct < n_sectors ? (off[sct + 1] - off[sct] + (uint32_t)kChunkSamples - 1u) / (uint32_t)kChunkSamples : 0u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_sum(v, lds, total);
+    if (sct < n_sectors)
+      chunk_begin[sct] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0)
+    chunk_begin[n_sectors] = carry;
+}
+
+// the sector of global chunk c (chunk_begin is ascending, sectors without samples own no chunk)
+__device__ __forceinline__ int mean_sector_of_chunk(const uint32_t *chunk_begin, int n_sectors, uint32_t c) {
+  int lo = 0, hi = n_sectors; // chunk_begin[lo] <= c < chunk_begin[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (chunk_begin[mid] <= c)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(kChunkThreads) lk_mean_chunk_sums_kernel(const float2 *xy, const uint32_t *off, const uint32_t *chunk_begin,
+                                                                          int n_sectors, long long *sums) {
+  __shared__ long long lds[2 * (kChunkThreads / kWave)];
+  const uint32_t c = blockIdx.x;
+  if (c >= chunk_begin[n_sectors])
+    return;
+  const int sct = mean_sector_of_chunk(chunk_begin, n_sectors, c);
+  const uint32_t b = off[sct] + (c - chunk_begin[sct]) * (uint32_t)kChunkSamples, e = min(off[sct + 1], b + (uint32_t)kChunkSamples);
+  long long sx = 0, sy = 0;
+  for (uint32_t i = b + threadIdx.x; i < e; i += kChunkThreads) { // (coalesced; the order of an exact sum is free)
+    const float2 q = xy[i];
+    sx += (long long)(int)q.x;
+    sy += (long long)(int)q.y;
+  }
+#pragma unroll
+  for (int d = kWave / 2; d > 0; d >>= 1) {
+    sx += __shfl_xor(sx, d, kWave);
+    sy += __shfl_xor(sy, d, kWave);
+  }
+  const int wave = (int)threadIdx.x / kWave;
+  if (((int)threadIdx.x & (kWave - 1)) == 0) {
+    lds[2 * wave] = sx;
+    lds[2 * wave + 1] = sy;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long tx = 0, ty = 0;
+    for (int w = 0; w < kChunkThreads / kWave; ++w) {
+      tx += lds[2 * w];
+      ty += lds[2 * w + 1];
+    }
+    sums[2 * (size_t)c] = tx;
+    sums[2 * (size_t)c + 1] = ty;
+  }
+}
+
+__global__ void __launch_bounds__(kChunkThreads) lk_mean_chunk_maps_kernel(const float2 *xy, const uint32_t *off, const uint32_t *chunk_begin,
+                                                                          int n_sectors, const long long *sums, MeanChunk *chunks) {
+  constexpr int WAVES = kChunkThreads / kWave;
+  __shared__ int lds_x[3 * WAVES], lds_y[3 * WAVES];
+  __shared__ long long lds_p[2 * WAVES];
+  const uint32_t c = blockIdx.x;
+  if (c >= chunk_begin[n_sectors])
+    return;
+  const int sct = mean_sector_of_chunk(chunk_begin, n_sectors, c);
+  const uint32_t c0 = chunk_begin[sct];
+  const uint32_t b = off[sct] + (c - c0) * (uint32_t)kChunkSamples, e = min(off[sct + 1], b + (uint32_t)kChunkSamples);
+  // exact prefix sums of the sector's earlier chunks
+  long long px = 0, py = 0;
+  for (uint32_t k = c0 + threadIdx.x; k < c; k += kChunkThreads) {
+    px += sums[2 * (size_t)k];
+    py += sums[2 * (size_t)k + 1];
+  }
+#pragma unroll
+  for (int d = kWave / 2; d > 0; d >>= 1) {
+    px += __shfl_xor(px, d, kWave);
+    py += __shfl_xor(py, d, kWave);
+  }
+  const int tid = (int)threadIdx.x, wave = tid / kWave;
+  if ((tid & (kWave - 1)) == 0) {
+    lds_p[2 * wave] = px;
+    lds_p[2 * wave + 1] = py;
+  }
+  __syncthreads();
+  px = py = 0;
+  for (int w = 0; w < WAVES; ++w) {
+    px += lds_p[2 * w];
+    py += lds_p[2 * w + 1];
+  }
+  AxisPass ax, ay;
+  ax.begin(px);
+  ay.begin(py);
+  const bool map_x = px + sums[2 * (size_t)c] < ax.limit, map_y = py + sums[2 * (size_t)c + 1] < ay.limit;
+  if (map_x || map_y) { // (uniform over the workgroup)
+    const uint32_t i0 = b + (uint32_t)tid * kMeanItems;
+#pragma unroll
+    for (int j = 0; j < kMeanItems; ++j) {
+      const uint32_t i = i0 + j;
+      if (i < e) {
+        const float2 q = xy[i];
+        ax.add((int)q.x);
+        ay.add((int)q.y);
+      }
+    }
+  }
+  ParityMap all_x, all_y;
+  (void)workgroup_prefix<kChunkThreads>(ax.m, lds_x, all_x);
+  (void)workgroup_prefix<kChunkThreads>(ay.m, lds_y, all_y);
+  if (tid == 0) {
+    MeanChunk m;
+    m.gx0 = all_x.g0, m.gx1 = all_x.g1, m.pnx = all_x.pn, m.shx = map_x ? ax.sh : -1;
+    m.gy0 = all_y.g0, m.gy1 = all_y.g1, m.pny = all_y.pn, m.shy = map_y ? ay.sh : -1;
+    chunks[c] = m;
+  }
+}
+
 __global__ void __launch_bounds__(kMeanThreads) lk_mean_center_int_kernel(const float2 *xy, const uint32_t *off, int n_sectors,
+                                                                          const uint32_t *chunk_begin, const MeanChunk *chunks,
                                                                           float2 *center) {
   constexpr int WAVES = kMeanThreads / kWave;
   __shared__ int lds_x[3 * WAVES], lds_y[3 * WAVES], lds_first[WAVES];
   __shared__ long long lds_l[3];
+  __shared__ MeanChunk lds_chunks[kMeanThreads];
+  __shared__ long long lds_walk[3]; // sx, sy, chunks taken
   const int sec = (int)blockIdx.x;
   if (sec >= n_sectors)
     return;
   const uint32_t b = off[sec], e = off[sec + 1];
   const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   long long sx = 0, sy = 0;
-  uint32_t k = b;
-  while (k < e) { // uniform over the workgroup
-    AxisPass ax, ay;
-    ax.begin(sx);
-    ay.begin(sy);
-    const uint32_t i0 = k + (uint32_t)tid * kMeanItems;
-    short x[kMeanItems], y[kMeanItems]; // (kept for the walk; coordinates are below 2^15 in any image this engine takes)
-    int n_mine = 0;
+
+  // the exact passes over [k, k_end): workgroup-uniform
+  auto walk = [&](uint32_t k, const uint32_t k_end) {
+    while (k < k_end) {
+      AxisPass ax, ay;
+      ax.begin(sx);
+      ay.begin(sy);
+      const uint32_t i0 = k + (uint32_t)tid * kMeanItems;
+      short x[kMeanItems], y[kMeanItems]; // (kept for the walk; coordinates are below 2^15 in any image this engine takes)
+      int n_mine = 0;
 #pragma unroll
-    for (int j = 0; j < kMeanItems; ++j) {
-      const uint32_t i = i0 + j;
-      x[j] = y[j] = 0;
-      if (i < e) {
-        const float2 q = xy[i];
-        x[j] = (short)(int)q.x;
-        y[j] = (short)(int)q.y;
-        ax.add((int)q.x);
-        ay.add((int)q.y);
-        ++n_mine;
-      }
-    }
-    __syncthreads(); // (the previous pass is done with lds)
-    ParityMap all_x, all_y;
-    const ParityMap ex = workgroup_prefix(ax.m, lds_x, all_x);
-    const ParityMap ey = workgroup_prefix(ay.m, lds_y, all_y);
-    const int gx_before = ax.p_start ? ex.g1 : ex.g0, px_mine = (ex.pn >> ax.p_start) & 1;
-    const int gy_before = ay.p_start ? ey.g1 : ey.g0, py_mine = (ey.pn >> ay.p_start) & 1;
-    const bool crosses = sx + ((long long)(gx_before + (px_mine ? ax.m.g1 : ax.m.g0)) << ax.sh) >= ax.limit ||
-                         sy + ((long long)(gy_before + (py_mine ? ay.m.g1 : ay.m.g0)) << ay.sh) >= ay.limit;
-    // the first run whose end leaves a binade, on either axis
-    const unsigned long long cb = __ballot(crosses);
-    if (lane == 0)
-      lds_first[wave] = cb ? wave * kWave + (int)__builtin_ctzll(cb) : kMeanThreads;
-    __syncthreads();
-    int first = kMeanThreads;
-    for (int w = 0; w < WAVES; ++w)
-      first = min(first, lds_first[w]);
-    if (first == kMeanThreads) { // the whole pass stays inside both binades
-      sx += (long long)(ax.p_start ? all_x.g1 : all_x.g0) << ax.sh;
-      sy += (long long)(ay.p_start ? all_y.g1 : all_y.g0) << ay.sh;
-      k += kMeanThreads * kMeanItems;
-      continue;
-    }
-    if (tid == first) { // my start is still inside both: walk to the first crossing with the exact rule
-      long long vx = sx + ((long long)gx_before << ax.sh), vy = sy + ((long long)gy_before << ay.sh);
-      int j = 0;
-      for (; j < n_mine; ++j) {
-        vx = rne24(vx + (long long)x[j]);
-        vy = rne24(vy + (long long)y[j]);
-        if (vx >= ax.limit || vy >= ay.limit) {
-          ++j;
-          break;
+      for (int j = 0; j < kMeanItems; ++j) {
+        const uint32_t i = i0 + j;
+        x[j] = y[j] = 0;
+        if (i < k_end) {
+          const float2 q = xy[i];
+          x[j] = (short)(int)q.x;
+          y[j] = (short)(int)q.y;
+          ax.add((int)q.x);
+          ay.add((int)q.y);
+          ++n_mine;
         }
       }
-      lds_l[0] = vx;
-      lds_l[1] = vy;
-      lds_l[2] = (long long)(i0 + (uint32_t)j);
+      __syncthreads(); // (the previous pass is done with lds)
+      ParityMap all_x, all_y;
+      const ParityMap ex = workgroup_prefix(ax.m, lds_x, all_x);
+      const ParityMap ey = workgroup_prefix(ay.m, lds_y, all_y);
+      const int gx_before = ax.p_start ? ex.g1 : ex.g0, px_mine = (ex.pn >> ax.p_start) & 1;
+      const int gy_before = ay.p_start ? ey.g1 : ey.g0, py_mine = (ey.pn >> ay.p_start) & 1;
+      const bool crosses = sx + ((long long)(gx_before + (px_mine ? ax.m.g1 : ax.m.g0)) << ax.sh) >= ax.limit ||
+                           sy + ((long long)(gy_before + (py_mine ? ay.m.g1 : ay.m.g0)) << ay.sh) >= ay.limit;
+      // the first run whose end leaves a binade, on either axis
+      const unsigned long long cb = __ballot(crosses);
+      if (lane == 0)
+        lds_first[wave] = cb ? wave * kWave + (int)__builtin_ctzll(cb) : kMeanThreads;
+      __syncthreads();
+      int first = kMeanThreads;
+      for (int w = 0; w < WAVES; ++w)
+        first = min(first, lds_first[w]);
+      if (first == kMeanThreads) { // the whole pass stays inside both binades
+        sx += (long long)(ax.p_start ? all_x.g1 : all_x.g0) << ax.sh;
+        sy += (long long)(ay.p_start ? all_y.g1 : all_y.g0) << ay.sh;
+        k += kMeanThreads * kMeanItems;
+        continue;
+      }
+      if (tid == first) { // my start is still inside both: walk to the first crossing with the exact rule
+        long long vx = sx + ((long long)gx_before << ax.sh), vy = sy + ((long long)gy_before << ay.sh);
+        int j = 0;
+        for (; j < n_mine; ++j) {
+          vx = rne24(vx + (long long)x[j]);
+          vy = rne24(vy + (long long)y[j]);
+          if (vx >= ax.limit || vy >= ay.limit) {
+            ++j;
+            break;
+          }
+        }
+        lds_l[0] = vx;
+        lds_l[1] = vy;
+        lds_l[2] = (long long)(i0 + (uint32_t)j);
+      }
+      __syncthreads();
+      sx = lds_l[0];
+      sy = lds_l[1];
+      k = (uint32_t)lds_l[2];
     }
+  };
+
+  const uint32_t c0 = chunk_begin[sec], n_chunks = chunk_begin[sec + 1] - c0;
+  uint32_t done = 0; // chunks of this sector behind the chain
+  while (done < n_chunks) {
+    // a tile of chunk records into LDS, then one thread takes as many of them as apply
+    const uint32_t tile = min(n_chunks - done, (uint32_t)kMeanThreads);
     __syncthreads();
-    sx = lds_l[0];
-    sy = lds_l[1];
-    k = (uint32_t)lds_l[2];
+    if ((uint32_t)tid < tile)
+      lds_chunks[tid] = chunks[c0 + done + (uint32_t)tid];
+    __syncthreads();
+    uint32_t at = 0;
+    while (at < tile) {
+      if (tid == 0) {
+        long long vx = sx, vy = sy;
+        uint32_t t = at;
+        for (; t < tile; ++t) {
+          const MeanChunk m = lds_chunks[t];
+          AxisPass ax, ay;
+          ax.begin(vx);
+          ay.begin(vy);
+          if (m.shx != ax.sh || m.shy != ay.sh)
+            break;
+          const long long nx = vx + ((long long)(ax.p_start ? m.gx1 : m.gx0) << ax.sh);
+          const long long ny = vy + ((long long)(ay.p_start ? m.gy1 : m.gy0) << ay.sh);
+          if (nx >= ax.limit || ny >= ay.limit)
+            break;
+          vx = nx;
+          vy = ny;
+        }
+        lds_walk[0] = vx;
+        lds_walk[1] = vy;
+        lds_walk[2] = (long long)t;
+      }
+      __syncthreads();
+      sx = lds_walk[0];
+      sy = lds_walk[1];
+      at = (uint32_t)lds_walk[2];
+      __syncthreads();
+      if (at < tile) { // this chunk needs the exact passes
+        const uint32_t kb = b + (done + at) * (uint32_t)kChunkSamples;
+        walk(kb, min(e, kb + (uint32_t)kChunkSamples));
+        ++at;
+      }
+    }
+    done += tile;
   }
   if (threadIdx.x == 0) {
     const float n = (float)(e - b);
@@ -3153,10 +3353,26 @@ hipError_t lk_launch_roi_fill(const LkRoiSector *sectors, const LkRoiFlat *flats
 }
 
 // integer, non-negative sample lists (device-masked annular / blob sectors): the same mean, evaluated in parallel
-hipError_t lk_launch_mean_center_int(const float2 *xy, const uint32_t *off, int n_sectors, float2 *center, hipStream_t st) {
+// scratch: lk_mean_center_int_scratch_bytes(total, n_sectors) bytes (chunk table, exact chunk sums, chunk maps)
+size_t lk_mean_center_int_scratch_bytes(uint32_t n_samples, int n_sectors) {
+  const size_t max_chunks = (size_t)n_samples / kChunkSamples + (size_t)n_sectors + 1;
+  return ((size_t)n_sectors + 2) * sizeof(uint32_t) + 8 + max_chunks * (2 * sizeof(long long) + sizeof(MeanChunk));
+}
+hipError_t lk_launch_mean_center_int(const float2 *xy, const uint32_t *off, uint32_t n_samples, int n_sectors, void *scratch,
+                                     float2 *center, hipStream_t st) {
   if (n_sectors <= 0)
     return hipSuccess;
-  hipLaunchKernelGGL(lk_mean_center_int_kernel, dim3((unsigned)n_sectors), dim3(kMeanThreads), 0, st, xy, off, n_sectors, center);
+  const size_t max_chunks = (size_t)n_samples / kChunkSamples + (size_t)n_sectors + 1;
+  uint32_t *chunk_begin = static_cast<uint32_t *>(scratch);
+  const size_t table = (((size_t)n_sectors + 2) * sizeof(uint32_t) + 7) & ~(size_t)7;
+  long long *sums = reinterpret_cast<long long *>(static_cast<char *>(scratch) + table);
+  MeanChunk *chunks = reinterpret_cast<MeanChunk *>(sums + 2 * max_chunks);
+  hipLaunchKernelGGL(lk_mean_chunk_table_kernel, dim3(1), dim3(1024), 0, st, off, n_sectors, chunk_begin);
+  hipLaunchKernelGGL(lk_mean_chunk_sums_kernel, dim3((unsigned)max_chunks), dim3(kChunkThreads), 0, st, xy, off, chunk_begin, n_sectors, sums);
+  hipLaunchKernelGGL(lk_mean_chunk_maps_kernel, dim3((unsigned)max_chunks), dim3(kChunkThreads), 0, st, xy, off, chunk_begin, n_sectors,
+                     sums, chunks);
+  hipLaunchKernelGGL(lk_mean_center_int_kernel, dim3((unsigned)n_sectors), dim3(kMeanThreads), 0, st, xy, off, n_sectors, chunk_begin,
+                     chunks, center);
   return hipGetLastError();
 }
 
