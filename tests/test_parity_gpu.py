@@ -1654,3 +1654,42 @@ def test_device_roi_masks_equal_the_host_scans(oracle, monkeypatch):
         e.commit_sectors()
         assert np.array_equal(e.getUndXY0ToCPU(0), g[f"{name}_pts"].astype(np.float32)), name
     e.close()
+
+
+@pytest.mark.gpu
+def test_mean_centre_of_long_integer_lists_is_the_sequential_float_mean():
+    """The centre of a device-masked sector is the reference's SEQUENTIAL float32 mean of its list
+    (pyramid_class.cpp:325-340), evaluated in parallel: exact chunk sums, parity maps for the predicted binade,
+    one verifying walk (lk_mean_center_int_kernel).  Lists built to stress it - many binade crossings (large
+    coordinates), none (small ones), crossings on one axis only, x sweeping the whole 15-bit range, lengths
+    around the 8192-sample chunk and the 32768-sample pass - against numpy's sequential float32 accumulate on
+    the very list the engine holds."""
+    def rect(x0, y0, x1, y1):
+        return np.float32([[x0, y0], [x1, y0], [x1, y1], [x0, y1]])
+
+    shapes = [rect(30000.2, 10.3, 32001.7, 700.6),      # 1.4 M samples, sums up to 4e10 / 5e8
+              rect(1.5, 1.5, 600.4, 500.2),             # small coordinates: long exact stretch, few crossings
+              rect(0.3, 5.2, 32700.8, 7.9),             # x sweeps the range, y is tiny
+              rect(20000.4, 30000.1, 20090.9, 30090.7), # both large, 8281 samples: just over one chunk
+              rect(16384.5, 100.5, 16511.4, 356.6),     # 127 x 256 = 32512: just under one pass
+              rect(5.5, 32000.5, 2500.4, 32700.4)]      # x small, y large
+    e = ca.HipCorrelationEngine(py_stop=1)
+    for s, c in enumerate(shapes):
+        e.resetPolygon_blob(s, c)
+    e.commit_sectors()
+    total = 0
+    for s in range(len(shapes)):
+        xy = e.getUndXY0ToCPU(s)
+        n, cx, cy = e.sector_info(s)
+        assert n == len(xy) and n > 8000
+        total += n
+        assert (xy == np.floor(xy)).all() and xy.min() >= 0 and xy.max() < 32768
+        want_x = np.add.accumulate(xy[:, 0], dtype=np.float32)[-1] / np.float32(n)
+        want_y = np.add.accumulate(xy[:, 1], dtype=np.float32)[-1] / np.float32(n)
+        assert np.float32(cx) == want_x and np.float32(cy) == want_y, (s, n, cx, cy, want_x, want_y)
+        # (and the sequential float mean is visibly NOT the exact mean on the long lists)
+        if n > 1000000:
+            assert abs(float(want_x) - float(xy[:, 0].astype(np.float64).mean())) > 1e-3
+    assert total > 1500000
+    e.close()
+
