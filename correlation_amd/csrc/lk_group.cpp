@@ -8,7 +8,9 @@
 // one-thread-per-device model of ncclCommInitAll - so the collectives rendezvous without
 // ncclGroupStart/End.  No host thread ever waits for another one inside a job, except in the
 // one-GPU rehearsal mode (the same device listed several times), where device-to-device copies
-// and a host barrier stand in for the two collectives.
+// and a host barrier stand in for the two collectives.  What can fail on one member alone (device allocations)
+// runs in a job of its own BEFORE the job that issues a collective, so that no member enters a collective the
+// others never reach; the argument checks of the engine calls fail on all members alike.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -317,9 +319,17 @@ static int set_image_any(lk_group *g, int slot, const void *src, bool on_device0
     return LK_ERROR_BAD_DOMAIN;
   if (slot < 0 || slot > 2 || !src || rows < 1 || cols < 1 || step < cols)
     return g->fail(LK_ERROR_BAD_DOMAIN, "lk_group_set_image: bad arguments");
-  return g->run([=](Member &me) -> int {
-    if (int rc = ensure_frame(g, me, slot, (size_t)rows * (size_t)cols))
+  // Growing the frame buffers can fail on one device alone (out of memory); a member that gave up before the
+  // broadcast would leave the others' collective waiting for ever.  So allocations get a job of their own, and
+  // the job with the collective starts only when every member has its buffer.
+  const size_t bytes = (size_t)rows * (size_t)cols;
+  bool grow = false;
+  for (const Member &me : g->m)
+    grow = grow || me.frame_cap[slot] < bytes;
+  if (grow)
+    if (int rc = g->run([=](Member &me) -> int { return ensure_frame(g, me, slot, bytes); }))
       return rc;
+  return g->run([=](Member &me) -> int {
     if (me.rank == 0)
       GHIP(hipMemcpy2DAsync(me.d_frame[slot], (size_t)cols, src, (size_t)step, (size_t)cols, (size_t)rows,
                             on_device0 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, me.st));
