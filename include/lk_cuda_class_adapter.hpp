@@ -10,6 +10,7 @@
 //   set_fitting_model / set_interpolation_model  :1677-1685       stored, applied at (re)create
 //   resetImagePyramids(und,def,nxt,color,start,step,stop) :915    lk_create + lk_set_image x3
 //   resetNextPyramid(path)              manager_class.cpp:257     lk_set_image(LK_IMG_NXT)
+//   tempQ (preloaded frames)            mainapp.cpp:926-954       preloadNextImage / resetNextPyramid()
 //   makeUndPyramidFromDef / makeDefPyramidFromNxt    :194,:234    lk_rotate_*
 //   resetPolygon(iSector,x0,y0,x1,y1)                :340         lk_set_sector_rect
 //   resetPolygon(iSector,r,dr,a,da,cx,cy,as)         :610         lk_set_sector_annular
@@ -36,6 +37,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <queue>
 #include <string>
 #include <utility>
 #include <vector>
@@ -166,7 +168,35 @@ public:
   errorEnum resetNextPyramid(const uint8_t *nxt, int rows, int cols, int step) {
     return ensure_engine() ? (errorEnum)set_image(LK_IMG_NXT, nxt, rows, cols, step) : error_cuda;
   }
+  // The preload queue (CudaClass::tempQ, cuda_class.cuh:79): MainApp::loadNxtGpuImages (mainapp.cpp:926-954) decodes
+  // frames 2.. ahead of time and pushes them; resetNextPyramid takes the front instead of decoding
+  // (cuda_class.cu:532-552).  Here as decoded 8-bit frames: preloadNextImage() pushes a copy, resetNextPyramid()
+  // without arguments uploads the front and pops it (error_bad_domain when the queue is empty).  With
+  // LK_ADAPTER_WITH_OPENCV the reference's own member - std::queue<cv::Mat> tempQ - exists as well and the
+  // path-based resetNextPyramid prefers it, exactly as the reference does.
+  struct PreloadedFrame {
+    std::vector<uint8_t> pixels; // dense rows
+    int rows = 0, cols = 0;
+  };
+  std::queue<PreloadedFrame> preloaded;
+  void preloadNextImage(const uint8_t *pixels, int rows, int cols, int step) {
+    PreloadedFrame f;
+    f.rows = rows, f.cols = cols;
+    f.pixels.resize((size_t)rows * (size_t)cols);
+    for (int r = 0; r < rows; ++r)
+      std::memcpy(f.pixels.data() + (size_t)r * (size_t)cols, pixels + (size_t)r * (size_t)step, (size_t)cols);
+    preloaded.push(std::move(f));
+  }
+  errorEnum resetNextPyramid() {
+    if (preloaded.empty())
+      return (errorEnum)LK_ERROR_BAD_DOMAIN;
+    const PreloadedFrame &f = preloaded.front();
+    const errorEnum rc = resetNextPyramid(f.pixels.data(), f.rows, f.cols, f.cols);
+    preloaded.pop();
+    return rc;
+  }
 #ifdef LK_ADAPTER_WITH_OPENCV
+  std::queue<cv::Mat> tempQ;
   void resetImagePyramids(const std::string undPath, const std::string defPath, const std::string nxtPath,
                           colorEnum color, const int start, const int step, const int stop) {
     cv::Mat u = cv::imread(undPath, cv::IMREAD_GRAYSCALE), d = cv::imread(defPath, cv::IMREAD_GRAYSCALE);
@@ -175,7 +205,13 @@ public:
                        start, step, stop);
   }
   void resetNextPyramid(const std::string nxtPath) {
-    cv::Mat n = cv::imread(nxtPath, cv::IMREAD_GRAYSCALE);
+    cv::Mat n;
+    if (tempQ.empty()) {
+      n = cv::imread(nxtPath, cv::IMREAD_GRAYSCALE);
+    } else {
+      n = tempQ.front();
+      tempQ.pop();
+    }
     resetNextPyramid(n.data, n.rows, n.cols, (int)n.step1());
   }
 #endif

@@ -84,6 +84,13 @@ int main(int argc, char **argv) {
         guess[(size_t)6 * s + i] = all[s].resultingParameters[i];
     }
   }
+  // the preload queue (CudaClass::tempQ): the next frame comes from the queue, pushed ahead of time
+  if (c.resetNextPyramid() == error_none) // nothing preloaded yet: must be refused
+    return 10;
+  c.preloadNextImage(nxt.data(), rows, cols, cols);
+  c.preloadNextImage(def.data(), rows, cols, cols); // (a second one stays queued)
+  if (c.resetNextPyramid() != error_none || c.preloaded.size() != 1)
+    return 11;
   c.makeDefPyramidFromNxt();
   for (int iSector = 0; iSector < S; ++iSector) {
     c.updatePolygon(iSector, def_Lagrangian);

@@ -55,8 +55,9 @@ def test_adapter_against_the_mock_in_manager_order(tmp_path):
     for s in range(S):   # frame 0: register, commit (once per sector), solve - sector after sector
         assert j[k].startswith(f"set_rect {s} ") and j[k + 1] == f"commit S={s + 1}" and j[k + 2] == f"correlate {s} guess=(0,0)"
         k += 3
-    assert j[k] == "def_from_nxt"
-    k += 1
+    assert j[k].split()[1] == "slot=2"        # the preload queue (CudaClass::tempQ): the queued frame goes to the next-image slot
+    assert j[k + 1] == "def_from_nxt"
+    k += 2
     rec = np.fromfile(out, ca.RESULT_DTYPE).reshape(2, S)
     for s in range(S):   # frame 1: every sector moves by its OWN frame-0 record and starts from it
         assert j[k].startswith(f"update {s} mode=1 solved=1 ")
