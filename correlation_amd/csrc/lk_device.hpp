@@ -29,7 +29,7 @@ struct LkHandoff {
   uint32_t n_evals, n_sample_evals, n_point_iters;
 };
 
-constexpr int kLkMidWords = 32; // Cold (22) + p (6) + phase
+constexpr int kLkMidWords = 32; // Cold (23) + p (6) + phase
 
 struct LkSolveArgs {
   const LkLevelView *lv; // [LK_MAX_LEVELS] in device memory

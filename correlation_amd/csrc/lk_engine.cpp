@@ -243,7 +243,7 @@ struct lk_engine {
   DevBuf<uint32_t> d_mid, d_finish_list, d_finish_count; // stragglers of the starved-level kernel
   DevBuf<uint32_t> d_ill_list, d_ill_count;              // sectors whose damped system met a bad pivot
   DevBuf<uint32_t> d_mean_scratch;                       // chunk table / sums / maps of lk_mean_center_int_kernel
-  int eval_cap = 32; // evaluations a lane of the starved-level kernel spends on one sector (0: no cap)
+  int eval_cap = 20; // evaluations a lane of the starved-level kernel spends on one sector (0: no cap; config 4: 12 / 16 / 20 / 24 / 32 -> 2.00 / 1.91 / 1.88 / 1.92 / 2.08 ms)
   int team_w = 0; // workgroups per sector of the team class
   int team_min_samples = 0; // per-sector team sizing (0: every team has team_w workgroups)
   DevBuf<float> d_team_partials;

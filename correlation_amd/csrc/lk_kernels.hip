@@ -1347,6 +1347,7 @@ struct Cold {
   int iteration, reached, error, level, level_old, s, use_saved;
   uint32_t n_evals, n_sample_evals, n_point_iters;
   uint32_t n_ill; // damped solves that met a bad pivot (well-conditioned speckle: 0)
+  int sums_kept;  // the sums of the evaluation at lg_p are in the sector's cache (kernel instances with KEEP_SUMS)
 };
 constexpr int kColdWords = sizeof(Cold) / 4;
 
@@ -1401,9 +1402,41 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
   constexpr int RED_WORDS = GROUP > kWave ? (THREADS / kWave) * (SumsT::N + 1) + 1 : 1;
   __shared__ float lds[RED_WORDS];
   __shared__ __attribute__((aligned(16))) float ord_lds[ORD ? ord_floats<SumsT::N, ORD ? GROUP : 16>() : 4];
-  __shared__ uint32_t cold_lds[COLD_IN_LDS ? (THREADS / GROUP) * kColdWords : 1];
-  uint32_t *cold_slot = cold_lds + (COLD_IN_LDS ? ((int)threadIdx.x / GROUP) * kColdWords : 0);
+  // The sums of the last ACCEPTED evaluation stay with the sector (small groups: behind its cold state in LDS; one
+  // lane per sector: in registers).  A rejected trip continues from the last good parameters with a larger lambda;
+  // the reference evaluates there once more (correlation_class.cpp:441-499) and gets, of course, the sums it had
+  // before.  With the sums kept the rejected trip is just another solve - from THOSE sums - inside the step that
+  // rejected: one evaluation fewer per rejection (config 4: 5.0 of 31.1 evaluations per sector, config 5: 6.1 of
+  // 35.7), same bits.  (After a sector changed hands in the middle of a level - parked and resumed by another
+  // launch - the cache is empty and the first rejection takes the re-evaluation, as the large groups always do.)
+  constexpr bool KEEP_SUMS = GROUP == 1 || GROUP == 16;
+  constexpr int kSlotWords = kColdWords + (KEEP_SUMS && COLD_IN_LDS ? SumsT::N : 0);
+  __shared__ uint32_t cold_lds[COLD_IN_LDS ? (THREADS / GROUP) * kSlotWords : 1];
+  uint32_t *cold_slot = cold_lds + (COLD_IN_LDS ? ((int)threadIdx.x / GROUP) * kSlotWords : 0);
   ColdStore<COLD_IN_LDS> cold;
+  float kept_reg[KEEP_SUMS && !COLD_IN_LDS ? SumsT::N : 1]; // (one lane per sector)
+  auto keep_sums = [&](const SumsT &v) {
+    if constexpr (KEEP_SUMS) {
+#pragma unroll
+      for (int i = 0; i < SumsT::N; ++i) {
+        if constexpr (COLD_IN_LDS)
+          cold_slot[kColdWords + i] = __float_as_uint(v.v[i]);
+        else
+          kept_reg[i] = v.v[i];
+      }
+    }
+  };
+  auto kept_sums = [&](SumsT &v) {
+    if constexpr (KEEP_SUMS) {
+#pragma unroll
+      for (int i = 0; i < SumsT::N; ++i) {
+        if constexpr (COLD_IN_LDS)
+          v.v[i] = __uint_as_float(cold_slot[kColdWords + i]);
+        else
+          v.v[i] = kept_reg[i];
+      }
+    }
+  };
 
   float p[6];
 #pragma unroll
@@ -1492,6 +1525,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
     k.error = LK_ERROR_NONE;
     k.lambda = 0.0001f;
     k.lg_chi = FLT_MAX;
+    k.sums_kept = 0;
     level_context(k);
 #pragma unroll
     for (int i = 0; i < P; ++i)
@@ -1588,7 +1622,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
       // a batch of an aligned persistent wavefront is over: back to one sector per row
       if (width != 16 && a.align && a.persistent && may_fetch) {
         width = 16;
-        cold_slot = cold_lds + ((int)threadIdx.x / GROUP) * kColdWords;
+        cold_slot = cold_lds + ((int)threadIdx.x / GROUP) * kSlotWords;
       }
     }
 #ifdef LK_TRACE_FINE
@@ -1638,6 +1672,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
           for (int i = 0; i < 6; ++i)
             p[i] = __uint_as_float(m[kColdWords + i]);
           phase = (int)m[kColdWords + 6];
+          k.sums_kept = 0; // (the sums did not travel with the parked sector)
           level_context(k);
           cold.store(cold_slot, k);
         } else {
@@ -1721,7 +1756,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
           take(phase);
           take(cur_level);
           if (!active)
-            cold_slot = cold_lds + (((int)threadIdx.x / GROUP) ^ 1) * kColdWords;
+            cold_slot = cold_lds + (((int)threadIdx.x / GROUP) ^ 1) * kSlotWords;
           active = true;
           wide = true;
         }
@@ -1845,8 +1880,37 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
         }
       } else {
         const float chi = S.v[SumsT::N - 1] * c.scaling;
-        const float lam_use = phase == PH_TENT ? fmaxf(k.lambda * 0.4f, min_lambda) : k.lambda;
-        float tent[P]; // the parameters this evaluation ran at
+        float lam_use = phase == PH_TENT ? fmaxf(k.lambda * 0.4f, min_lambda) : k.lambda;
+        // KEEP_SUMS: a tentative evaluation that is rejected, has not converged and may go on (the tests of the PH_TENT
+        // branch and of iter_start below, taken before the solve: they need chi only) continues at once from the
+        // kept sums of the last good parameters with the larger lambda - the bookkeeping of the rejection, of the next
+        // trip's start and of the reference's second evaluation there, whose sums are the kept ones, in one step.
+        bool redo = false;
+        if constexpr (KEEP_SUMS) {
+          if (phase == PH_TENT && k.sums_kept != 0 && !(chi <= k.lg_chi)) {
+            const float delta_chi = __builtin_fabsf((k.lg_chi - chi) / (fmaxf(k.lg_chi, chi) + a.precision));
+            const float lambda_new = fminf(k.lambda * 10.0f, max_lambda);
+            redo = !(delta_chi < a.precision) && !(k.iteration + 1 > a.max_iters || lambda_new >= max_lambda);
+            if (redo) {
+              k.lambda = lambda_new;
+              k.use_saved = 0;
+              ++k.iteration;
+              k.reached = k.iteration;
+              ++k.n_point_iters;
+              lam_use = lambda_new;
+#pragma unroll
+              for (int i = 0; i < P; ++i)
+                p[i] = k.lg_p[i];
+            }
+          }
+          // (the cache is written here, before the solve, so that the sums are dead after it: accepted evaluations -
+          // known from chi - and the first evaluation of a level / a re-evaluation, which ran at lg_p)
+          if (phase != PH_TENT || chi <= k.lg_chi)
+            keep_sums(S);
+          if (redo) // (those lanes solve from their kept sums; chi of this evaluation is already taken)
+            kept_sums(S);
+        }
+        float tent[P]; // the parameters this solve starts from: where the evaluation ran, or (redo) the last good ones
 #pragma unroll
         for (int i = 0; i < P; ++i)
           tent[i] = p[i];
@@ -1869,22 +1933,35 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
 #pragma unroll
             for (int i = 0; i < P; ++i)
               p[i] = tent[i];
-            --k.n_evals;
-            k.n_sample_evals -= (uint32_t)c.n;
+            if (redo) { // (the evaluation of this step stands; what the SAFE kernel repeats is the one at the last good parameters)
+              phase = PH_REEVAL;
+            } else {
+              --k.n_evals;
+              k.n_sample_evals -= (uint32_t)c.n;
+            }
+            k.sums_kept = 0;
             park(k, a.ill_list, a.ill_count);
             ill_parked = true;
           }
         }
         if (ill_parked) {
           // nothing else happens to this sector in this launch
+        } else if (redo) {
+          phase = PH_TENT; // p now holds the tentative parameters of the next trip
         } else if (phase == PH_EVAL0) {
           ++k.n_point_iters;
           k.lg_chi = chi;
           k.use_saved = 1;
           k.iteration = 1;
           iter_start = true;
+          if constexpr (KEEP_SUMS) { // (lg_p = where this evaluation ran, enter_level)
+            k.sums_kept = 1;
+          }
         } else if (phase == PH_REEVAL) {
           phase = PH_TENT; // p now holds the tentative parameters
+          if constexpr (KEEP_SUMS) {
+            k.sums_kept = 1;
+          }
         } else {           // PH_TENT: p now holds the look-ahead ("saved") parameters
           const float delta_chi =
               __builtin_fabsf((k.lg_chi - chi) / (fmaxf(k.lg_chi, chi) + a.precision));
@@ -1895,6 +1972,9 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
             for (int i = 0; i < P; ++i)
               k.lg_p[i] = tent[i];
             k.use_saved = 1;
+            if constexpr (KEEP_SUMS) {
+              k.sums_kept = 1;
+            }
           } else {
             k.lambda = fminf(k.lambda * 10.0f, max_lambda);
             k.use_saved = 0;
