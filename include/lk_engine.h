@@ -130,7 +130,7 @@ int lk_set_batch_invariant(lk_engine *e, int enabled);
  * are also independent of batch composition.  The sample work stays parallel (a 16-lane row or a
  * wavefront per sector forms the per-sample products and transposes them through LDS; only the
  * additions of each sum run as a chain), so the mode costs 1.4-2.7x the default's time (measured:
- * config 2 0.66 against 0.245 ms, config 4 3.1 against 2.3 ms, config 5 16 against 6 ms), not the
+ * config 2 0.54-0.65 against 0.24 ms, config 4 3.2 against 1.9 ms, config 5 15 against 5.6 ms), not the
  * serial loop's.  threads = 0 (default): lane-parallel sums and the root-free Cholesky solve,
  * which differ from the reference by summation order and solver rounding only.
  * May be called at any time; the lane groups are re-chosen before the next solve. */
