@@ -428,6 +428,8 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
       const unsigned long long badmask = __ballot(bad);
       // Lanes without a sample (j >= n, or a sample that left the image) hold t = +0, and a sum
       // that started at +0 is never -0, so adding their +0 changes no bit: no select needed.
+      // (Stopping at the longest list of the wavefront's rows - config 4's level 2 has 1-4 samples - was tried: the
+      // early exit keeps the compiler from scheduling the 2P x 28 broadcast-adds as one block, config 4 1.9 -> 3.7 ms.)
 #pragma unroll
       for (int j = 0; j < 2 * P; ++j) {
 #pragma unroll
@@ -1438,6 +1440,17 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
     }
   };
 
+  // the per-level pointer table in LDS: a level change then costs ONE global round trip (the sector's rectangle /
+  // list offsets) instead of two (the table entry of its level first)
+  __shared__ LkLevelView lv_lds[LK_MAX_LEVELS];
+  {
+    constexpr int WORDS = (int)(sizeof(LkLevelView) / 4);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(a.lv);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(lv_lds);
+    for (int i = (int)threadIdx.x; i < WORDS * (a.py_stop + 1); i += THREADS)
+      dst[i] = src[i];
+    __syncthreads();
+  }
   float p[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i)
@@ -1465,7 +1478,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
       // of its slot leave at once (uniform over the workgroup, before any barrier)
       if (a.team_min_samples > 0 && team.slot < a.n_sectors) {
         const int sector = a.order ? (int)a.order[team.slot] : team.slot;
-        const LkLevelView lv0 = a.lv[0];
+        const LkLevelView lv0 = lv_lds[0];
         const int4 rc = lv0.rect[sector];
         const int n0 = rc.z > 0 ? rc.w : (int)(lv0.off[sector + 1] - lv0.off[sector]);
         int w = (n0 + a.team_min_samples - 1) / a.team_min_samples;
@@ -1478,7 +1491,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
   }
 
   auto level_count = [&](int level, int sector) -> int { // samples of a sector at a level
-    const LkLevelView lv = a.lv[level];
+    const LkLevelView lv = lv_lds[level];
     const int4 rc = lv.rect[sector];
     return rc.z > 0 ? rc.w : (int)(lv.off[sector + 1] - lv.off[sector]);
   };
@@ -1499,7 +1512,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
   };
 
   auto level_context = [&](const Cold &k) { // what the lanes need to know about the sector at k.level
-    const LkLevelView lv = a.lv[k.level];
+    const LkLevelView lv = lv_lds[k.level];
     cur_level = k.level;
     const uint32_t off = lv.off[k.s];
     const int4 rc = lv.rect[k.s];
@@ -1561,8 +1574,8 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
       for (int i = 0; i < 6; ++i)
         r.resultingParameters[i] = i < P ? p[i] : 0.f;
       r.chi = k.lg_chi;
-      const int4 rc0 = a.lv[0].rect[k.s];
-      r.numberOfPoints = rc0.z > 0 ? rc0.w : (int)(a.lv[0].off[k.s + 1] - a.lv[0].off[k.s]);
+      const int4 rc0 = lv_lds[0].rect[k.s];
+      r.numberOfPoints = rc0.z > 0 ? rc0.w : (int)(lv_lds[0].off[k.s + 1] - lv_lds[0].off[k.s]);
       // reference-order mode: the very first evaluation of the sector failed, so no LM trip ever ran -
       // the reference then reports whatever its reached_iterations member still holds from the sector
       // before (correlation_class.cpp:413-419, :870); lk_stale_iterations_kernel fills that in
