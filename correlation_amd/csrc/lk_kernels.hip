@@ -1728,7 +1728,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
         phase = PH_EXIT;
       }
     }
-#ifdef LK_TRACE_FINE
+#if defined(LK_TRACE_FINE) && !defined(LK_TRACE_TRANS)
     tr_fetch += __builtin_amdgcn_s_memtime() - tr_f0;
 #endif
     bool active = phase < PH_FETCH;
@@ -2000,6 +2000,9 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
           }
         }
       }
+#ifdef LK_TRACE_TRANS // (one-off split of the time after the solve: in place of the fetch block's cycles)
+      const unsigned long long tr_x0 = __builtin_amdgcn_s_memtime();
+#endif
       if (iter_start) { // top of the iteration loop (:441-499)
         if (k.iteration > a.max_iters || k.lambda >= max_lambda) {
           k.error = LK_ERROR_CORRELATION_MAX_ITERS_REACHED;
@@ -2039,6 +2042,9 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
         park(k, a.finish_list, a.finish_count);
       else
         cold.store(cold_slot, k);
+#ifdef LK_TRACE_TRANS
+      tr_fetch += __builtin_amdgcn_s_memtime() - tr_x0;
+#endif
     }
 #ifdef LK_TRACE_FINE
     tr_post += __builtin_amdgcn_s_memtime() - tr_p0;
