@@ -1806,6 +1806,8 @@ static LkSolveArgs base_args(lk_engine *e, const float *d_guess, lk_result *d_re
     return f ? std::atoi(f) : 1;
   }();
   a.align = align;
+  const char *ks = std::getenv("LK_KEEP_SUMS"); // test hook, read per call
+  a.keep_sums = ks ? (std::atoi(ks) != 0 ? 1 : 0) : 1;
   return a;
 }
 

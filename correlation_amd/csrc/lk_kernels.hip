@@ -1904,6 +1904,19 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
             const float delta_chi = __builtin_fabsf((k.lg_chi - chi) / (fmaxf(k.lg_chi, chi) + a.precision));
             const float lambda_new = fminf(k.lambda * 10.0f, max_lambda);
             redo = !(delta_chi < a.precision) && !(k.iteration + 1 > a.max_iters || lambda_new >= max_lambda);
+            if constexpr (!SAFE && !STARVED) {
+              // Fast flavour: the look-ahead solve on the rejected sums is useless for the trajectory, but a bad pivot
+              // in it hands the sector to the SAFE kernel - which then solves with its own pivot rule to the end.  WHO
+              // solves a sector must not depend on the cache, so the factorisation still runs here (rejections are rare
+              // on the levels this flavour sees), and on a bad pivot the step takes the ordinary path below.
+              if (redo && a.ill_list) {
+                float q[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                  q[i] = p[i];
+                redo = damped_step<P, false>(S, lam_use, c.scaling, q, false);
+              }
+            }
             if (redo) {
               k.lambda = lambda_new;
               k.use_saved = 0;
@@ -1968,12 +1981,12 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
           k.iteration = 1;
           iter_start = true;
           if constexpr (KEEP_SUMS) { // (lg_p = where this evaluation ran, enter_level)
-            k.sums_kept = 1;
+            k.sums_kept = a.keep_sums;
           }
         } else if (phase == PH_REEVAL) {
           phase = PH_TENT; // p now holds the tentative parameters
           if constexpr (KEEP_SUMS) {
-            k.sums_kept = 1;
+            k.sums_kept = a.keep_sums;
           }
         } else {           // PH_TENT: p now holds the look-ahead ("saved") parameters
           const float delta_chi =
@@ -1986,7 +1999,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) l
               k.lg_p[i] = tent[i];
             k.use_saved = 1;
             if constexpr (KEEP_SUMS) {
-              k.sums_kept = 1;
+              k.sums_kept = a.keep_sums;
             }
           } else {
             k.lambda = fminf(k.lambda * 10.0f, max_lambda);

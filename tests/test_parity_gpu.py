@@ -1693,3 +1693,39 @@ def test_mean_centre_of_long_integer_lists_is_the_sequential_float_mean():
     assert total > 1500000
     e.close()
 
+
+
+@pytest.mark.gpu
+def test_kept_sums_save_evaluations_and_change_no_record(monkeypatch):
+    """A rejected LM trip goes back to the last good parameters with a larger lambda.  The reference evaluates
+    there again (correlation_class.cpp:441-499) and gets the sums it had; the one-lane kernel and the 16-lane
+    groups keep those sums and solve from them at once.  With the cache switched off (LK_KEEP_SUMS=0) the engine
+    takes the reference's extra evaluation: every record must keep its bits, in the default flavour (batch-invariant,
+    so that records are comparable) and in reference-order mode, on sectors with singular coarse levels
+    (7 x 7 samples, 3 levels: config 4's geometry) where rejections are frequent."""
+    und, dfm = ca.speckle.speckle_pair(640, 640, p=(1.2, -0.6, 0.0004, 0.0, 0.0, -0.0002), seed=17)
+
+    def run(keep, reference_order):
+        monkeypatch.setenv("LK_KEEP_SUMS", "1" if keep else "0")
+        e = ca.HipCorrelationEngine(fitting_model=ca.FM_UVUXUYVXVY, py_stop=2)
+        e.set_batch_invariant(True)
+        e.set_reference_order(1 if reference_order else 0)
+        e.set_undeformed_image(und)
+        e.set_deformed_image(dfm)
+        e.set_rect_grid(24.0, 24.0, 615.0, 615.0, 66, 66)          # 4356 sectors of 7 x 7 samples
+        e.commit_sectors()
+        assert e.sector_info(0)[0] == 49
+        rec = e.correlate_all(np.zeros(6, np.float32))
+        st, per = e.stats(), e.sector_stats()
+        e.close()
+        return rec, st, per
+
+    for reference_order in (False, True):
+        with_cache, st1, per1 = run(True, reference_order)
+        without, st0, per0 = run(False, reference_order)
+        assert with_cache.tobytes() == without.tobytes(), reference_order
+        assert st1["point_iterations"] == st0["point_iterations"]                 # the LM trips are the same trips
+        assert (per1[:, 0] <= per0[:, 0]).all()                                   # never more evaluations with the cache
+        saved = st0["evaluations"] - st1["evaluations"]
+        assert saved > 0.08 * st0["evaluations"], (saved, st0["evaluations"])     # (config 4: 16 %)
+        assert st1["evaluations"] >= st1["point_iterations"]                     # at least one evaluation per LM trip and level
