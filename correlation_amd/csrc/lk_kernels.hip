@@ -1382,13 +1382,16 @@ template <bool IN_LDS> struct ColdStore {
 #ifndef LK_MIN_WAVES
 #define LK_MIN_WAVES 1
 #endif
+#ifndef LK_MIN_WAVES_512 // wavefronts per SIMD the 512-thread instances must fit (4: two workgroups per CU, 128 VGPRs)
+#define LK_MIN_WAVES_512 1
+#endif
 #ifdef LK_TRACE
 // tuning builds only (scripts/tune_build.sh NAME -DLK_TRACE): per-wavefront timeline of a solve launch,
 // 8 words per workgroup: start, end, cycles inside evaluate<>, steps, HW_ID, XCC_ID, first sector, -
 __device__ unsigned long long g_lk_trace[8 * 16384];
 #endif
 template <int MODEL, int INTERP, int GROUP, int THREADS, bool SAFE>
-__global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : 1)) lk_solve_kernel(LkSolveArgs a) {
+__global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : THREADS == 512 ? LK_MIN_WAVES_512 : 1)) lk_solve_kernel(LkSolveArgs a) {
   constexpr int P = n_params(MODEL);
   using SumsT = Sums<P>;
   constexpr bool COLD_IN_LDS = GROUP > 1 && GROUP <= kWave;
