@@ -580,6 +580,12 @@ def test_error_paths(oracle, speckle512):
     assert got0["error_code"][0] == want0["error_code"] == 3
     assert np.allclose(got0["p"][0], want0["p"], atol=1e-4)
     e0.close()
+    # per-sector counters before any sector is committed: an error, not garbage
+    e1 = ca.HipCorrelationEngine(fitting_model=ca.FM_UV)
+    with pytest.raises(ca.LkError) as err:
+        e1.sector_stats()
+    assert err.value.code == ca.ERROR_BAD_DOMAIN and "no committed sectors" in str(err.value)
+    e1.close()
 
 
 def test_annular_and_blob_sectors(oracle):
