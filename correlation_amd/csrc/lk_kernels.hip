@@ -1083,22 +1083,23 @@ __device__ __forceinline__ void colpiv_qr_solve_row16(const float (&M)[N * N], c
     for (int r = k + 1; r < N; ++r)
       tailSq += col[r] * col[r];
     const float c0 = col[k];
+    // (both sides of every data-dependent branch of this step are computed and the result selected: the row is
+    // bound by the LENGTH of this chain of dependent operations, not by their number, and straight-line code lets the
+    // square roots and divisions of the Householder vector, of tau and of the norm down-dating overlap)
     float beta, tau, ess[N];
-    if (tailSq <= FLT_MIN) {
-      tau = 0.f;
-      beta = c0;
+    {
+      const bool tiny = tailSq <= FLT_MIN;
+      float b = __builtin_sqrtf(c0 * c0 + tailSq);
+      b = c0 >= 0.f ? -b : b;
+      const float den = c0 - b;
 #pragma unroll
-      for (int r = k + 1; r < N; ++r)
-        ess[r] = 0.f;
-    } else {
-      beta = __builtin_sqrtf(c0 * c0 + tailSq);
-      if (c0 >= 0.f)
-        beta = -beta;
-      const float den = c0 - beta;
-#pragma unroll
-      for (int r = k + 1; r < N; ++r)
-        ess[r] = col[r] / den;
-      tau = (beta - c0) / beta;
+      for (int r = k + 1; r < N; ++r) {
+        const float e = col[r] / den;
+        ess[r] = tiny ? 0.f : e;
+      }
+      const float t = (b - c0) / b;
+      tau = tiny ? 0.f : t;
+      beta = tiny ? c0 : b;
     }
     const int pl = owner[k];
     const bool i_am_pivot = me == pl;
@@ -1113,40 +1114,35 @@ __device__ __forceinline__ void colpiv_qr_solve_row16(const float (&M)[N * N], c
         col[r] = ess[r];
     }
     const bool later = pos > k && me < N; // my column is still to the right of the pivot
-    if (N - k > 1 && hc[k] != 0.f) {
+    if (N - k > 1) {
       float tmp = 0.f;
 #pragma unroll
       for (int r = k + 1; r < N; ++r)
         tmp += vk[k][r] * col[r];
       tmp += col[k];
       const float ck = col[k] - hc[k] * tmp;
-      float cr[N];
+      const bool apply = later && hc[k] != 0.f;
+      col[k] = apply ? ck : col[k];
 #pragma unroll
-      for (int r = k + 1; r < N; ++r)
-        cr[r] = col[r] - tmp * (hc[k] * vk[k][r]);
-      if (later) {
-        col[k] = ck;
-#pragma unroll
-        for (int r = k + 1; r < N; ++r)
-          col[r] = cr[r];
+      for (int r = k + 1; r < N; ++r) {
+        const float cr = col[r] - tmp * (hc[k] * vk[k][r]);
+        col[r] = apply ? cr : col[r];
       }
     }
-    if (later && normU != 0.f) { // norm down-dating of my column
+    { // norm down-dating of my column
       float temp = __builtin_fabsf(col[k]) / normU;
       temp = (1.f + temp) * (1.f - temp);
       temp = temp < 0.f ? 0.f : temp;
       const float ratio = normU / normD;
       const float temp2 = temp * (ratio * ratio);
-      if (temp2 <= norm_downdate_threshold) {
-        float s = 0.f;
+      float s = 0.f;
 #pragma unroll
-        for (int r = k + 1; r < N; ++r)
-          s += col[r] * col[r];
-        normD = __builtin_sqrtf(s);
-        normU = normD;
-      } else {
-        normU *= __builtin_sqrtf(temp);
-      }
+      for (int r = k + 1; r < N; ++r)
+        s += col[r] * col[r];
+      const float fresh = __builtin_sqrtf(s), scaled = normU * __builtin_sqrtf(temp);
+      const bool live = later && normU != 0.f, recompute = temp2 <= norm_downdate_threshold;
+      normD = live && recompute ? fresh : normD;
+      normU = live ? (recompute ? fresh : scaled) : normU;
     }
   }
   if (nonzero_pivots == 0) {
@@ -1177,13 +1173,21 @@ __device__ __forceinline__ void colpiv_qr_solve_row16(const float (&M)[N * N], c
       }
     }
   }
+  // the triangular factor, gathered from the lanes that own its columns before the (sequential) back-substitution
+  // needs it: 21 independent permutes in flight at once instead of one round trip per use
+  float R[N][N];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int r = 0; r <= i; ++r)
+      R[i][r] = from(col[r], owner[i]);
 #pragma unroll
   for (int i = N - 1; i >= 0; --i) {
     if (i < nonzero_pivots) {
-      cv[i] = cv[i] / from(col[i], owner[i]);
+      cv[i] = cv[i] / R[i][i];
 #pragma unroll
       for (int r = 0; r < i; ++r)
-        cv[r] -= cv[i] * from(col[r], owner[i]);
+        cv[r] -= cv[i] * R[i][r];
     } else {
       cv[i] = 0.f;
     }
