@@ -1,5 +1,7 @@
+#!/usr/bin/env python3
+"""Registration + commit time of config 3's 64-vertex star blob (4.2 M samples) on fresh engines."""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import correlation_amd as ca
 ang = 2 * np.pi * np.arange(64) / 64

@@ -1,5 +1,7 @@
+#!/usr/bin/env python3
+"""Records with and without the kept sums (LK_KEEP_SUMS): which sectors differ, and how (none must)."""
 import os, sys, numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import correlation_amd as ca
 und, dfm = ca.speckle.speckle_pair(640, 640, p=(1.2, -0.6, 0.0004, 0.0, 0.0, -0.0002), seed=17)
 def run(keep, ro, cap=None, ill=None):
