@@ -1423,7 +1423,9 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : THREA
   __shared__ uint32_t cold_lds[COLD_IN_LDS ? (THREADS / GROUP) * kSlotWords : 1];
   uint32_t *cold_slot = cold_lds + (COLD_IN_LDS ? ((int)threadIdx.x / GROUP) * kSlotWords : 0);
   ColdStore<COLD_IN_LDS> cold;
-  float kept_reg[KEEP_SUMS && !COLD_IN_LDS ? SumsT::N : 1]; // (one lane per sector)
+  // (one lane per sector: a column of LDS per lane - 28 more registers would cost the kernel a wavefront per SIMD,
+  // and config 5's 3100 wavefronts of it a second round)
+  __shared__ float kept_lds[KEEP_SUMS && !COLD_IN_LDS ? SumsT::N * THREADS : 1];
   auto keep_sums = [&](const SumsT &v) {
     if constexpr (KEEP_SUMS) {
 #pragma unroll
@@ -1431,7 +1433,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : THREA
         if constexpr (COLD_IN_LDS)
           cold_slot[kColdWords + i] = __float_as_uint(v.v[i]);
         else
-          kept_reg[i] = v.v[i];
+          kept_lds[i * THREADS + (int)threadIdx.x] = v.v[i];
       }
     }
   };
@@ -1442,7 +1444,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : THREA
         if constexpr (COLD_IN_LDS)
           v.v[i] = __uint_as_float(cold_slot[kColdWords + i]);
         else
-          v.v[i] = kept_reg[i];
+          v.v[i] = kept_lds[i * THREADS + (int)threadIdx.x];
       }
     }
   };
