@@ -70,6 +70,7 @@ struct LkSolveArgs {
   int reference_order;   // T > 0 (SAFE 16- / 64-lane kernels): every level with the reference's summation order for
                          //   number_of_threads = T and its QR - bit-identical records (lk_set_reference_order)
   int persistent;        // 1: groups pull sectors from `queue`; 0: one sector per group by position
+  int starved_max;       // a level with at most this many samples is "starved" (default 2 P)
   int keep_sums;         // 1 (default): a rejected trip continues from the kept sums of the last good parameters;
                          //   0 (LK_KEEP_SUMS=0, tests): it evaluates there again, as the reference does - same records
   int gpu_share;         // launches that may hold the GPU at the same time (>= 1): bounds a team launch's width

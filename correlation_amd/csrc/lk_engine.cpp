@@ -877,6 +877,10 @@ int lk_set_sector_points(lk_engine *e, int sector, const float *xy, int n, int u
 // Starved levels (at most 2P samples for P parameters; always the coarsest ones) are solved
 // first by the one-lane-per-sector kernel, bit-identically to the reference.  Needs h_class,
 // h_rect and h_off of the coarsest level.
+static int starved_max(const lk_engine *e) { // samples up to which a level counts as starved
+  static const int env = [] { const char *f = std::getenv("LK_STARVED_MAX"); return f ? std::atoi(f) : -1; }(); // tuning hook
+  return env >= 0 ? env : 2 * e->P;
+}
 static int refresh_starved(lk_engine *e) {
   const int S = (int)e->h_class.size();
   for (int c = 0; c < kNumClasses; ++c)
@@ -888,7 +892,7 @@ static int refresh_starved(lk_engine *e) {
   for (int s = 0; s < S; ++s) {
     const int4 r = e->h_rect[l][(size_t)s];
     const int n = r.z > 0 ? r.w : (int)(e->h_off[l][(size_t)s + 1] - e->h_off[l][(size_t)s]);
-    if (n <= 2 * e->P)
+    if (n <= starved_max(e))
       e->class_starved[e->h_class[(size_t)s]] = any_starved = true;
   }
   if (any_starved) {
@@ -1808,6 +1812,7 @@ static LkSolveArgs base_args(lk_engine *e, const float *d_guess, lk_result *d_re
   a.align = align;
   const char *ks = std::getenv("LK_KEEP_SUMS"); // test hook, read per call
   a.keep_sums = ks ? (std::atoi(ks) != 0 ? 1 : 0) : 1;
+  a.starved_max = starved_max(e);
   return a;
 }
 

@@ -1727,7 +1727,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : THREA
         }
         if (k.level < a.py_start) {
           // finished by the starved-level kernel (result already written): take another
-        } else if (STARVED && level_count(k.level, k.s) > 2 * P) {
+        } else if (STARVED && level_count(k.level, k.s) > a.starved_max) {
           hand_over(k); // nothing starved here: the lane-group kernel does it all
         } else {
           enter_level(k);
@@ -2048,7 +2048,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : THREA
         if (k.level < a.py_start) {
           translate<P>(p, k.level_old, 0);
           finished = true;
-        } else if (starved && !ordered_all && level_count(k.level, k.s) > 2 * P) {
+        } else if (starved && !ordered_all && level_count(k.level, k.s) > a.starved_max) {
           handed = true;
         } else {
           enter_level(k);
