@@ -9,8 +9,12 @@
 //                      sector in the reference's summation order with the restated Eigen QR for
 //                      starved pyramid levels; SAFE 16-lane = the finisher of that kernel's
 //                      stragglers (ordered sums by row_newbcast, QR spread over the row).
+//                      Reference-order mode (lk_set_reference_order): the SAFE 16- / 64-lane instances
+//                      solve every level with evaluate_ordered (the CPU engine's summation order for any
+//                      number_of_threads) + that QR - records byte-identical to the CPU class.
 //                      Scheduling inside a wavefront: level alignment, solo (32 lanes) and adaptive
-//                      width (16 lanes) - idle lanes join the sectors still being solved.
+//                      width (16 lanes) - idle lanes join the sectors still being solved.  Kept sums:
+//                      a rejected LM trip continues from the sums of the last accepted evaluation.
 //                      Replaces kCorrelation + k_global_reduction + k_build_LS_problem_in_GPU0 +
 //                      cuSOLVER potrf/potrs + kScale + kUpdateParameters and the host loop of
 //                      CudaClass::correlate (cuda_class.cu:104-473, correlationKernel.cu,
@@ -19,8 +23,13 @@
 //   lk_pyramid2_kernel upload copy + pyramid levels 1 and 2 of one or two frames in one launch;
 //   lk_pyramid_kernel  one further level; both with the CPU engine's arithmetic
 //                      (pyramid_class.cpp:83-122), replacing k_pyramid_bw (kernels.cu:761).
-//   small utilities    level table upload, initial-guess policy, sample warping, stand-alone
-//                      evaluation / sampling / solve (known-answer entry points).
+//   lk_roi_*_kernel    annular / blob ROI masks with the CPU engine's predicates and sample order (tiles,
+//                      count -> offsets -> fill), replacing cudaPolygon's thrust mask + remove_if
+//                      (cuda_polygon.cuh:180-292); lk_mean_*: the sequential float mean centre of such
+//                      lists evaluated in parallel, bit for bit (parity maps per binade).
+//   lk_decimate_*, lk_rewarp_kernel   coarser-level lists and moved lists on the device (pyramid_class.cpp:289-323).
+//   small utilities    level table upload, initial-guess policy, sample warping, stale iteration counts
+//                      (reference-order mode), stand-alone evaluation / sampling / solve (known-answer entry points).
 //
 // This translation unit is compiled with -ffp-contract=off: the reference's x86-64 builds
 // have no FMA, and per-sample values (warp, bicubic value/gradient, residual, H) are kept
