@@ -35,6 +35,30 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+N_SIMDS, PEAK_CLOCK_HZ, VALU_ISSUE_CYCLES = 1024, 2.4e9, 2.0   # 256 CUs x 4 SIMDs; one wave64 f32 VALU instruction per 2 cycles per SIMD
+
+
+def profile_constants():
+    """Per-launch constants of the C2 solve kernels from the committed rocprofv3 --pmc passes (profiles/): HBM bytes
+    (FETCH_SIZE + WRITE_SIZE) and VALU wavefront-instructions (SQ_INSTS_VALU).  NOT counters read in this run."""
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                with open(path) as f:
+                    d = json.load(f)
+                d["file"] = f"profiles/{name}"
+                return d
+            except Exception:
+                pass
+    return {}
+
+
+def valu_issue_frac(valu_insts, kernel_ms):
+    """Share of the chip's VALU issue slots the launch used: instructions x 2 cycles / (1024 SIMDs x 2.4 GHz x time)."""
+    if not valu_insts or not kernel_ms:
+        return None
+    return valu_insts * VALU_ISSUE_CYCLES / (N_SIMDS * PEAK_CLOCK_HZ * kernel_ms * 1e-3)
 
 
 def cpu_baseline(wl, und, dfm, budget_sectors):
@@ -83,7 +107,35 @@ def other_configs(ca):
                    "evaluations_per_sector": st["evaluations"] / st["sectors"],
                    "error_free_fraction": float((r["error_code"] == 0).mean())}
 
-    def rect(wl, truth, seed):
+    def parity_block(wl, und, dfm, r):
+        """default mode against the CPU oracle (1 thread order) on every sector of a starved config: error codes,
+        NaN set, iteration counts, |dp01| (correlation_class.cpp:441-499, :552-587 on starved levels)"""
+        from oracle import lk_oracle as lo   # the checker - never the measured path
+        o = lo.Oracle(interp=lo.IM_BICUBIC, model=wl.model, py_stop=wl.py_stop)
+        o.set_image(0, np.asarray(und))
+        o.set_image(1, np.asarray(dfm))
+        xd, yd, cen = lo.rect_sector_geometry(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, wl.hs, wl.vs)
+        n = (2 * xd + 1) * (2 * yd + 1)
+        cat = np.concatenate([lo.rect_points(cx - xd, cy - yd, cx + xd, cy + yd) for cx, cy in cen])
+        t0 = time.perf_counter()
+        w = o.correlate_packed(cat, np.arange(len(cen), dtype=np.int64) * n, np.full(len(cen), n, np.int32),
+                               centers=cen.astype(np.float32), nthreads=os.cpu_count() or 1)
+        dt = time.perf_counter() - t0
+        nan_g, nan_w = np.isnan(r["p"]).any(1), np.isnan(w["p"]).any(1)
+        both = ~nan_g & ~nan_w & (r["error_code"] == 0) & (w["error_code"] == 0)
+        d = np.abs(r["p"][both][:, :2] - w["p"][both][:, :2]).max(1)
+        return {"sectors": int(len(w)), "oracle_seconds": dt,
+                "error_codes_differ": int((r["error_code"] != w["error_code"]).sum()),
+                "oracle_error_free": int((w["error_code"] == 0).sum()), "engine_error_free": int((r["error_code"] == 0).sum()),
+                "nan_records_engine": int(nan_g.sum()), "nan_records_oracle": int(nan_w.sum()),
+                "nan_set_differs": int((nan_g != nan_w).sum()),
+                "iterations_equal_fraction": float((r["iterations"] == w["iterations"]).mean()),
+                "abs_dp01_p50": float(np.percentile(d, 50)), "abs_dp01_p99": float(np.percentile(d, 99)),
+                "abs_dp01_max": float(d.max()),
+                "note": "default mode vs oracle(T=1); starved levels are chaotic in the reference itself "
+                        "(tests/test_parity_gpu.py: the same comparison with bounds on 3000-sector subsets)"}
+
+    def rect(wl, truth, seed, parity=False):
         und, dfm = ca.speckle.speckle_pair(wl.size, wl.size, p=truth, seed=seed, device="cuda")
         e = ca.HipCorrelationEngine(fitting_model=wl.model, py_stop=wl.py_stop)
         e.set_undeformed_image(und)
@@ -97,7 +149,15 @@ def other_configs(ca):
         m["median_abs_u_minus_truth"] = float(np.nanmedian(np.abs(r["p"][:, 0] - u_true)[ok]))
         m["nan_records"] = int(np.isnan(r["p"]).any(1).sum())   # singular starved levels: the reference's QR returns NaN too
         m["workload"] = wl.name
+        e.set_reference_order(1)
+        _, mr = timed(e)
+        m["reference_order_mode"] = {"solve_ms": mr["solve_ms"], "frac_of_hbm_peak": mr["algorithmic_GBps"] / HBM_PEAK_GBS}
         e.close()
+        if parity:
+            try:
+                m["parity_vs_cpu"] = parity_block(wl, und, dfm, r)
+            except Exception as ex:
+                m["parity_vs_cpu"] = {"error": repr(ex)}
         return m
 
     try:  # the opt-in separable evaluation of the same bicubic surface (include/lk_engine.h)
@@ -123,7 +183,7 @@ def other_configs(ca):
     except Exception as ex:
         out["C2_separable_bicubic"] = {"error": repr(ex)}
     try:
-        out["C4_one_pair"] = rect(C4, C4.truth, 7)
+        out["C4_one_pair"] = rect(C4, C4.truth, 7, parity=True)
     except Exception as ex:  # extra evidence must never take the headline line down
         out["C4_one_pair"] = {"error": repr(ex)}
     try:
@@ -160,6 +220,121 @@ def other_configs(ca):
     except Exception as ex:
         out["C3"] = {"error": repr(ex)}
     return out
+
+
+def sharded_config(ca, torch, dist, wl, rank, world, local_rank, steps, warmup):
+    """One pair of `wl` with its sector grid split over the ranks in contiguous blocks (the code path of
+    --workload): per step the deformed frame is broadcast from rank 0 (RCCL over xGMI), every rank builds both
+    pyramids and solves its shard, the 48-byte records are all-gathered.  Also times the WHOLE grid on one GPU
+    (every rank on its own device, no collectives) so that the ratio is in the same line.  Every rank must call
+    this; local failures are agreed on before any collective is entered."""
+    from correlation_amd.workload import shard_range
+    use_dist = dist is not None
+    dev = torch.device("cuda", local_rank)
+    info = {"workload": wl.name, "n_ranks": dist.get_world_size() if use_dist else 1, "sectors_total": wl.hs * wl.vs}
+    ok, err = 1, None
+    full = shard = None
+    try:
+        truth = wl.truth if wl.size <= 2048 else (1.3, -0.7, 0.0005, 0.0, 0.0, -0.00025)
+        und, dfm = ca.speckle.speckle_pair(wl.size, wl.size, p=truth, seed=7 if wl.size <= 2048 else 13,
+                                           device=f"cuda:{local_rank}" if wl.size > 2048 else None)
+        d_und = torch.from_numpy(und).to(dev)
+        d_def = torch.from_numpy(dfm).to(dev)
+        st_ = torch.cuda.Stream(dev)
+
+        def engine(first, count):
+            e = ca.HipCorrelationEngine(interpolation=ca.IM_BICUBIC, fitting_model=wl.model, py_stop=wl.py_stop, device=local_rank)
+            e.set_stream(st_.cuda_stream)
+            e.set_rect_grid(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, wl.hs, wl.vs, first, count)
+            e.commit_sectors()
+            e.set_timing(False)
+            return e
+        full = engine(0, wl.hs * wl.vs)
+        first, count = shard_range(wl.hs * wl.vs, rank, world)
+        shard = engine(first, count) if world > 1 else full
+        cap = (wl.hs * wl.vs + world - 1) // world
+        d_guess = torch.zeros((wl.hs * wl.vs, 6), dtype=torch.float32, device=dev)
+        d_rec_full = torch.zeros((wl.hs * wl.vs, 48), dtype=torch.uint8, device=dev)
+        d_rec = torch.zeros((cap, 48), dtype=torch.uint8, device=dev)
+        d_all = torch.empty((world, cap, 48), dtype=torch.uint8, device=dev)
+    except Exception as ex:   # noqa: BLE001 - reported in the block, never fatal for the headline
+        ok, err = 0, repr(ex)
+    if use_dist:
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok_all = int(flag.item())
+    else:
+        ok_all = ok
+    if not ok_all:
+        for e in {id(x): x for x in (full, shard) if x is not None}.values():
+            e.close()
+        info["error"] = err or "set-up failed on another rank"
+        return info
+    torch.cuda.set_stream(st_)
+
+    def timed(fn, n):
+        for _ in range(max(1, warmup)):
+            fn()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / n * 1e3
+
+    def one_gpu():
+        full.set_image_pair_device(d_und.data_ptr(), d_def.data_ptr(), wl.size, wl.size)
+        full.correlate_all_device(d_guess.data_ptr(), d_rec_full.data_ptr())
+
+    def sharded():
+        if use_dist:
+            dist.broadcast(d_def, src=0)
+        shard.set_image_pair_device(d_und.data_ptr(), d_def.data_ptr(), wl.size, wl.size)
+        shard.correlate_all_device(d_guess.data_ptr(), d_rec.data_ptr())
+        if use_dist:
+            dist.all_gather_into_tensor(d_all.view(-1, 48), d_rec)
+
+    ms1 = timed(one_gpu, steps)
+    full.set_timing(True)
+    one_gpu()
+    torch.cuda.synchronize(dev)
+    st1 = full.stats()
+    ms = timed(sharded, steps)
+    info.update({"ms_per_step": ms, "ms_per_step_1gpu": ms1, "speedup_vs_1gpu": ms1 / ms,
+                 "point_iterations_per_s": st1["point_iterations"] / (ms * 1e-3),
+                 "point_iterations_per_s_1gpu": st1["point_iterations"] / (ms1 * 1e-3),
+                 "sectors_per_rank": int(shard.n_sectors), "scaling": "strong",
+                 "step": "broadcast of the deformed frame + both pyramids + solve of the rank's block + all-gather of records"
+                         if use_dist else "both pyramids + solve of the whole grid (one rank: no collectives)"})
+    for e in {id(x): x for x in (full, shard)}.values():
+        e.close()
+    return info
+
+
+def native_group_child(args, workload):
+    """`bench.py --native` (include/lk_group.h: one process, ncclCommInitAll, one thread + stream per device) as a
+    CHILD process with a time limit, so that nothing it does can take this process - or the headline line - down."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--native", "--gpus", str(args.gpus), "--workload", workload,
+           "--steps", str(max(10, args.steps // 2)), "--warmup", str(max(3, args.warmup // 2))]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+        for ln in reversed(r.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                d = json.loads(ln)
+                return {"value": d["value"], "ms_per_step": d["ms_per_step"], "n_ranks": d["config"].get("n_ranks"),
+                        "scaling": d["scaling"], "workload": d["config"]["workload"], "parallelism": d["config"]["parallelism"],
+                        "solve_ms_slowest_member": d["roofline"]["kernel_ms"], "error_free_fraction": d["per_pair"]["error_free_fraction"]}
+        return {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+    except Exception as ex:   # noqa: BLE001
+        return {"error": repr(ex)}
 
 
 def native_group_bench(args, ca, wl):
@@ -202,7 +377,7 @@ def native_group_bench(args, ca, wl):
             "unit": "point-iterations/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl.name, "sectors_total": S, "parallelism": f"lk_group: one process, {n} device(s), "
+            "config": {"workload": wl.name, "sectors_total": S, "n_ranks": g.comm_ranks, "parallelism": f"lk_group: one process, {n} device(s), "
                        "one host thread + HIP stream per device, ncclBroadcast of frames, ncclAllGather of records",
                        "step": "broadcast + pyramid(und) + pyramid(def) on every device, sharded solve, record all-gather"},
             "roofline": {"bound": "hbm", "achieved": st["algorithmic_bytes"] / (st["solve_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS * n,
@@ -222,6 +397,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sectors", type=int, default=10000)
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-sharded-configs", action="store_true", help="skip the C2-strong / C4 / C5 sharded blocks")
+    ap.add_argument("--no-native-group", action="store_true", help="skip the lk_group (C-ABI, single process) block")
     ap.add_argument("--inflight", type=int, default=1,
                     help="image pairs in flight per GPU in the TIMED region (default 1: one pair at a time, the rate "
                          "of a tracked sequence and the run `roofline` describes).  P > 1: step k runs on engine "
@@ -458,35 +635,100 @@ def main():
         ms_r = r0.elapsed_time(r1) / n_r
         res_ref = d_rr.cpu().numpy().view(ca.RESULT_DTYPE).reshape(-1)
         st_rr = er.stats()
-        ref_order = {"solve_ms": ms_r, "point_iterations_per_s": st_rr["point_iterations"] / (ms_r * 1e-3),
+        pc_r = profile_constants()
+        ref_order = {"solve_ms": ms_r, "kernel_ms": ms_r, "point_iterations_per_s": st_rr["point_iterations"] / (ms_r * 1e-3),
                      "algorithmic_GBps": st_rr["algorithmic_bytes"] / (ms_r * 1e-3) / 1e9,
+                     "frac": st_rr["algorithmic_bytes"] / (ms_r * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "algorithmic_bytes_per_launch": st_rr["algorithmic_bytes"],
+                     "valu_issue_frac": valu_issue_frac(pc_r.get("reference_order_valu_insts_per_launch_C2"), ms_r),
+                     "traffic": pc_r.get("reference_order_hbm_bytes_per_launch_C2"),
+                     "kernel": "lk_solve_kernel<fm_UVUxUyVxVy, im_bicubic, 16 lanes, reference order>: K back-to-back launches "
+                               "between two HIP events on the engine's stream",
                      "note": "lk_set_reference_order(1): ordered sums + the restated QR at every level; records "
                              "bit-identical to the CPU oracle (see parity_vs_cpu)"}
         er.close()
         torch.cuda.set_stream(stream)
+
+    end_to_end = None
+    if world == 1 and not use_dist and not strong:
+        try:
+            ee = ca.HipCorrelationEngine(interpolation=ca.IM_BICUBIC, fitting_model=wl.model, py_stop=wl.py_stop, device=local_rank)
+            ee.set_rect_grid(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, wl.hs, wl.vs)
+            ee.commit_sectors()
+            g0 = np.zeros(6, np.float32)
+
+            def pair(two):
+                if two:
+                    ee.set_undeformed_image(und)
+                ee.set_deformed_image(dfm)
+                return ee.correlate_all(g0)      # guesses up, solve, 48-byte records down, synchronised
+
+            n_e = max(10, args.steps // 4)
+            out_ms = {}
+            for label, two in (("two_new_frames", True), ("one_new_frame", False)):
+                for _ in range(3):
+                    pair(two)
+                t0 = time.perf_counter()
+                for _ in range(n_e):
+                    pair(two)
+                out_ms[label] = (time.perf_counter() - t0) / n_e * 1e3
+            st_e = ee.stats()
+            end_to_end = {"ms_per_pair": out_ms["two_new_frames"], "ms_per_pair_one_new_frame": out_ms["one_new_frame"],
+                          "point_iterations_per_s": st_e["point_iterations"] / (out_ms["two_new_frames"] * 1e-3),
+                          "what": "host frames (pageable memory) -> lk_set_image upload + pyramids -> solve -> records copied back to "
+                                  "the host, one pair at a time, synchronous (BASELINE.md 4.3); `one_new_frame`: the undeformed frame "
+                                  "stays (a sequence with a fixed reference).  Never the reported `value`."}
+            ee.close()
+        except Exception as ex:   # noqa: BLE001
+            end_to_end = {"error": repr(ex)}
+
+    # ---- multi-GPU configs: one pair with the sector grid split over the ranks (every rank takes part) ----
+    sharded = {}
+    if not strong and not args.no_sharded_configs:
+        for key, w_ in (("C2_strong", C2), ("C4_sharded", C4), ("C5_sharded", C5)):
+            try:
+                sharded[key] = sharded_config(ca, torch, dist if use_dist else None, w_, rank, world, local_rank,
+                                              max(5, args.steps // 10), max(2, args.warmup // 10))
+            except Exception as ex:   # noqa: BLE001 (a failure after the ranks agreed: reported, the headline stands)
+                sharded[key] = {"error": repr(ex)}
+    native = None
+    if not strong and not args.no_native_group:
+        # the C-ABI group (one process, all devices) runs as a child of rank 0 while the other ranks keep off the GPUs:
+        # a host-only rendezvous through a file, bounded waits on both sides
+        flag_path = None
+        if use_dist:
+            tok = torch.tensor([int(time.time() * 1e3) % (1 << 30) if rank == 0 else 0], dtype=torch.int64, device=dev)
+            dist.broadcast(tok, src=0)
+            torch.cuda.synchronize(dev)
+            flag_path = os.path.join("/tmp", f"lk_bench_native_{int(tok.item())}.done")
+        if rank == 0:
+            native = native_group_child(args, "C2")
+            if flag_path:
+                with open(flag_path, "w") as f:
+                    f.write("done")
+        elif flag_path:
+            t_wait = time.time()
+            while not os.path.exists(flag_path) and time.time() - t_wait < 300:
+                time.sleep(0.2)
 
     if rank == 0:
         value = total_pit / dt_max
         achieved = st["algorithmic_bytes"] / (solve_avg_ms * 1e-3) / 1e9
         # HBM bytes per solve launch: a PROFILE CONSTANT from the PMC passes of this workload
         # (FETCH_SIZE + WRITE_SIZE, corrected; profiles/*_pmc_traffic.txt), not a counter read in this run
-        traffic, traffic_src = None, None
-        try:
-            if not strong:   # the PMC profile is of the C2 launch
-                for name in ("r02_traffic.json", "r01_traffic.json"):
-                    path = os.path.join(ROOT, "profiles", name)
-                    if os.path.exists(path):
-                        with open(path) as f:
-                            traffic = json.load(f)["solve_kernel_hbm_bytes_per_launch_C2"]
-                        traffic_src = f"profile constant: profiles/{name} (rocprofv3 --pmc passes), bytes per launch"
-                        break
-        except Exception:
-            pass
+        traffic, traffic_src, valu_frac = None, None, None
+        if not strong:   # the PMC profile is of the C2 launch
+            pc = profile_constants()
+            traffic = pc.get("solve_kernel_hbm_bytes_per_launch_C2")
+            if traffic is not None:
+                traffic_src = f"profile constant: {pc['file']} (rocprofv3 --pmc passes), bytes per launch"
+            valu_frac = valu_issue_frac(pc.get("solve_kernel_valu_insts_per_launch_C2"), solve_avg_ms)
         line = {
             "metric": "correlation-point-iterations/sec",
             "value": value,
             "unit": "point-iterations/s",
             "n_gpus": world,
+            "n_ranks": dist.get_world_size() if use_dist else 1,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt_max / args.steps,
@@ -508,6 +750,9 @@ def main():
                                     if not strong else
                                     "lk_solve_kernel<fm_UVUxUyVxVy, im_bicubic>: all launches of one solve"),
                          "kernel_ms": solve_avg_ms,
+                         "valu_issue_frac": valu_frac,
+                         "valu_issue_frac_is": "SQ_INSTS_VALU per launch (profile constant) x 2 cycles / (1024 SIMDs x 2.4 GHz x kernel_ms): "
+                                               "the binding limit of this kernel is VALU issue and the critical path of its slowest sectors, not HBM",
                          "measured": "K back-to-back solve launches of the engine and stream the timed region ran on, "
                                      "between two HIP events on that stream",
                          "algorithmic_bytes_per_launch": st["algorithmic_bytes"]},
@@ -523,6 +768,12 @@ def main():
             line["overlapped"] = overlapped
         if ref_order:
             line["reference_order_mode"] = ref_order
+        if end_to_end:
+            line["end_to_end"] = end_to_end
+        if sharded:
+            line["sharded_configs"] = sharded
+        if native is not None:
+            line["native_group"] = native
         if world == 1 and not args.no_cpu_baseline and not strong:
             base, nsec = cpu_baseline(wl, und, dfm, args.cpu_sectors)
             pit_per_sector = st["point_iterations"] / S

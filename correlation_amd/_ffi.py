@@ -90,6 +90,7 @@ SYMBOLS = {
     "lk_correlate": (C.c_int, [_P, C.c_int, _F, _P]),
     "lk_correlate_all": (C.c_int, [_P, _F, _P]),
     "lk_correlate_all_device": (C.c_int, [_P, _P, _P]),
+    "lk_get_results_device": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
     "lk_correlate_all_async": (C.c_int, [_P]),
     "lk_wait_results": (C.c_int, [_P, _P]),
     "lk_adjust_initial_guess": (C.c_int, [_P, C.c_int, C.c_int, _F, C.c_float, C.c_float]),
@@ -126,6 +127,7 @@ SYMBOLS = {
     "lk_group_destroy": (None, [_P]),
     "lk_group_last_error_string": (C.c_char_p, [_P]),
     "lk_group_size": (C.c_int, [_P]),
+    "lk_group_comm_ranks": (C.c_int, [_P]),
     "lk_group_engine": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
     "lk_group_shard": (C.c_int, [_P, C.c_int, _I, _I]),
     "lk_group_shard_range": (C.c_int, [C.c_int, C.c_int, C.c_int, _I, _I]),

@@ -114,6 +114,22 @@ struct LkRewarpArgs { // level-0 sample lists moved by the last level-0 evaluati
   uint32_t total;          // dst_off[S]
 };
 
+// One rectangular sector appended behind the committed ones (lk_commit_sectors' fast path): everything the
+// device needs to know about it travels in the kernel arguments.
+struct LkAppendArgs {
+  int sector, n_levels;
+  int keep_state; // 1: a committed rectangle that moved (lk_update_sector): rectangles and centre only
+  float2 center;
+  float2 *d_center;
+  float *d_guess, *d_last_p, *d_prev_p, *d_last_eval_p; // [S][6] sequence state: zeroed
+  lk_result *d_result;                                   // [S]: zeroed
+  uint32_t *d_stats;                                     // [S][4]: zeroed
+  int4 rect[LK_MAX_LEVELS];        // per committed level (in list order): the sector's implicit rectangle
+  uint32_t off_end[LK_MAX_LEVELS]; //   and off[sector + 1] (= off[sector]: a rectangle has no list entries)
+  int4 *d_rect[LK_MAX_LEVELS];
+  uint32_t *d_off[LK_MAX_LEVELS];
+};
+
 struct LkEvalArgs { // stand-alone evaluation (known-answer tests)
   const LkLevelView *lv;
   const float2 *center;

@@ -13,6 +13,7 @@
 // (16 / 32 / 64 lanes, 4 / 8 wavefronts, teams) on one stream, preceded by the one-lane kernel
 // and its finisher when the class has a starved pyramid level.
 #include "lk_device.hpp"
+#include "lk_internal.hpp"
 #include "lk_roi.hpp"
 
 #include <rocprofiler-sdk-roctx/roctx.h>
@@ -50,6 +51,7 @@ hipError_t lk_launch_roi_count(const LkRoiSector *sectors, const LkRoiFlat *flat
 hipError_t lk_launch_roi_fill(const LkRoiSector *sectors, const LkRoiFlat *flats, const uint32_t *tile_begin, int n_sectors,
                               uint32_t n_tiles, const uint32_t *tiles, float2 *xy, uint32_t *off, hipStream_t st);
 hipError_t lk_launch_stale_iterations(lk_result *r, int n, const int *carry_in, int *carry_out, hipStream_t st);
+hipError_t lk_launch_append_sector(const LkAppendArgs &a, hipStream_t st);
 hipError_t lk_launch_mean_center(const float2 *xy, const uint32_t *off, int n_sectors, float2 *center, hipStream_t st);
 size_t lk_mean_center_int_scratch_bytes(uint32_t n_samples, int n_sectors);
 hipError_t lk_launch_mean_center_int(const float2 *xy, const uint32_t *off, uint32_t n_samples, int n_sectors, void *scratch,
@@ -159,6 +161,12 @@ template <class T> struct DevBuf {
     n = want;
     return e;
   }
+  // the same with room to spare (sector-by-sector registration: lk_commit_sectors' append path)
+  hipError_t reserve_keep(size_t want, size_t keep) {
+    if (want <= n && p)
+      return hipSuccess;
+    return ensure_keep(std::max(want, 2 * n + 64), keep);
+  }
   void release() {
     if (p)
       (void)hipFree(p);
@@ -196,6 +204,7 @@ struct lk_engine {
   bool batch_invariant = false; // lk_set_batch_invariant
   DevBuf<int> d_stale;          // reference-order mode: reached_iterations as the last solved sector left it ([2], alternating)
   int stale_par = 0;
+  bool defer_stale = false;     // lk_group member: the markers are resolved over the gathered records, in global sector order
   int reference_order = 0;      // lk_set_reference_order: 0 = off, T = the reference's number_of_threads to reproduce
   int pairs_in_flight = 1;      // lk_set_pairs_in_flight: launches that share the GPU
   bool timing = true; // HIP events around pyramid builds and solves (lk_stats.solve_ms / pyramid_ms)
@@ -210,6 +219,12 @@ struct lk_engine {
   std::vector<HostSector> hs; // staging until commit
   std::vector<HostSector> hs_backup; // the lists before the last lk_translate / lk_rewarp_sectors
   bool committed = false;
+  // Sector-by-sector registration (the reference's first-frame loop: resetPolygon(i), correlate(i),
+  // manager_class.cpp:340, :449): a commit that only ADDS rectangles behind the committed ones appends them
+  // (O(1) host work and one small launch per sector) instead of rebuilding everything; the size-class
+  // analysis of the whole domain is then redone lazily, by the next batch solve.
+  bool append_ok = false;     // the committed state can be extended in place (plain sectors, no pending rebuilds)
+  bool classes_dirty = false; // h_order / class_begin / promotions are stale (sectors were appended)
   bool recommit_pending = false; // lk_update_sector moved sample lists: rebuild before the next solve
   // lk_rewarp_sectors rebuilds the lists on the device: hs[].xy / cx / cy are stale until a host
   // consumer asks for them (materialize_host); the previous level-0 lists stay in d_xy0_alt
@@ -243,6 +258,7 @@ struct lk_engine {
   DevBuf<uint32_t> d_mid, d_finish_list, d_finish_count; // stragglers of the starved-level kernel
   DevBuf<uint32_t> d_ill_list, d_ill_count;              // sectors whose damped system met a bad pivot
   DevBuf<uint32_t> d_mean_scratch;                       // chunk table / sums / maps of lk_mean_center_int_kernel
+  int starved_max = -1; // LK_STARVED_MAX as read by the last commit (-1: the default, 2 P)
   int eval_cap = 20; // evaluations a lane of the starved-level kernel spends on one sector (0: no cap; config 4: 12 / 16 / 20 / 24 / 32 -> 2.00 / 1.91 / 1.88 / 1.92 / 2.08 ms)
   int team_w = 0; // workgroups per sector of the team class
   int team_min_samples = 0; // per-sector team sizing (0: every team has team_w workgroups)
@@ -680,6 +696,7 @@ int lk_clear_sectors(lk_engine *e) {
   e->lists_on_device = e->backup_on_device = false;
   e->hs.clear();
   e->committed = false;
+  e->append_ok = false;
   e->S = 0;
   return LK_ERROR_NONE;
 }
@@ -696,6 +713,8 @@ static HostSector *sector_slot(lk_engine *e, int sector) {
     return nullptr;
   if ((size_t)sector >= e->hs.size())
     e->hs.resize((size_t)sector + 1);
+  if (sector < e->S)
+    e->append_ok = false; // a committed sector is registered anew: the next commit rebuilds
   e->committed = false;
   e->hs[(size_t)sector].fresh = true;
   e->hs[(size_t)sector].lazy = 0; // (annular / blob registration sets it again)
@@ -739,6 +758,7 @@ int lk_set_rect_grid(lk_engine *e, float x_begin, float y_begin, float x_end, fl
   e->hs.clear();
   e->hs.resize((size_t)count);
   e->committed = false;
+  e->append_ok = false;
   for (int k = 0; k < count; ++k) {
     int iSector = first + k, i = iSector / vs, j = iSector % vs; // iSector = i*vs + j
     HostSector &s = e->hs[(size_t)k];
@@ -877,12 +897,15 @@ int lk_set_sector_points(lk_engine *e, int sector, const float *xy, int n, int u
 // Starved levels (at most 2P samples for P parameters; always the coarsest ones) are solved
 // first by the one-lane-per-sector kernel, bit-identically to the reference.  Needs h_class,
 // h_rect and h_off of the coarsest level.
-static int starved_max(const lk_engine *e) { // samples up to which a level counts as starved
-  static const int env = [] { const char *f = std::getenv("LK_STARVED_MAX"); return f ? std::atoi(f) : -1; }(); // tuning hook
-  return env >= 0 ? env : 2 * e->P;
-}
+// (the tuning hook LK_STARVED_MAX is read at every commit and kept with the engine: the host's class table and
+// the kernel's hand-over rule must agree)
+static int starved_max(const lk_engine *e) { return e->starved_max >= 0 ? e->starved_max : 2 * e->P; }
 static int refresh_starved(lk_engine *e) {
   const int S = (int)e->h_class.size();
+  {
+    const char *f = std::getenv("LK_STARVED_MAX"); // tuning hook (tests/tools/c4_parity.py)
+    e->starved_max = f ? std::atoi(f) : -1;
+  }
   for (int c = 0; c < kNumClasses; ++c)
     e->class_starved[c] = false;
   if (const char *f = std::getenv("LK_FORCE_SAFE")) // tuning / test hook
@@ -1032,6 +1055,101 @@ static int build_lists_roi_device(lk_engine *e, const std::vector<int> &levels) 
 
 // keep_state: a re-commit after the sample lists moved (Lagrangian descriptions) keeps the
 // sequence state of the sectors (guess history, last results)
+// Size classes -> lanes per sector, the launch order of the classes, starved-level flags and team widths of the
+// committed domain (e->S sectors; needs h_rect / h_off).  Part of every full commit; after sectors were APPENDED
+// (lk_commit_sectors' fast path) it is redone lazily by the next batch solve.
+static int classify_sectors(lk_engine *e) {
+  const int S = e->S;
+  // size classes -> lanes per sector.  A class whose sectors are too few to fill the chip
+  // (< 2048 wavefronts) and still large per lane is promoted to the next wider group.
+  e->h_class.assign((size_t)S, 0);
+  size_t cnt[kNumClasses] = {0, 0, 0, 0, 0, 0}, tot[kNumClasses] = {0, 0, 0, 0, 0, 0};
+  for (int s = 0; s < S; ++s) {
+    int n0 = level0_count(e, s), c = size_class(n0);
+    e->h_class[(size_t)s] = c;
+    cnt[c]++;
+    tot[c] += (size_t)n0;
+  }
+  for (int c = 0; c + 1 < kTeamClass; ++c) { // (nothing is promoted into the team class)
+    if (!cnt[c] || e->batch_invariant || e->reference_order > 0) // (the group depends on the sector alone)
+      continue;
+    // Wider groups shorten a sector's own critical path and cost lane packing: they pay only
+    // while the narrow grouping leaves SIMDs without a wavefront (fewer wavefronts than the
+    // 1024 SIMDs).  Measured on 19x19-sample sectors (scripts/quick_solve.py, LK_GRID /
+    // LK_FORCE_GROUP): 1024 sectors 0.110 ms in 32-lane groups against 0.092 ms in 64-lane ones,
+    // 2025 sectors 0.122 / 0.123, 4096 sectors 0.166 / 0.188, 8100 sectors 0.240 / 0.324.
+    size_t waves = cnt[c] * (size_t)kGroupOfClass[c] / 64 * (size_t)e->pairs_in_flight; // (the other launches' too)
+    size_t per_lane = tot[c] / cnt[c] / (size_t)kGroupOfClass[c];
+    const bool small_group = kGroupOfClass[c] < 64;
+    const size_t enough = kGroupOfClass[c] == 16 ? 4096 : 1024; // (16-lane groups: 10 000 sectors 0.31 against 0.27 ms)
+    if ((small_group && waves < enough && per_lane >= 4) || (!small_group && waves < 2048 && per_lane >= 32)) {
+      for (int s = 0; s < S; ++s)
+        if (e->h_class[(size_t)s] == c)
+          e->h_class[(size_t)s] = c + 1;
+      cnt[c + 1] += cnt[c];
+      tot[c + 1] += tot[c];
+      cnt[c] = tot[c] = 0;
+    }
+  }
+  if (const char *f = std::getenv("LK_FORCE_GROUP")) { // tuning experiments only
+    int g = std::atoi(f);
+    for (int c = 0; c < kNumClasses; ++c)
+      if (kGroupOfClass[c] == g)
+        std::fill(e->h_class.begin(), e->h_class.end(), c);
+  }
+  int force_team = 0;
+  if (const char *f = std::getenv("LK_FORCE_TEAM")) { // test hook: every sector gets a team of this width
+    force_team = std::atoi(f);
+    if (force_team >= 1) // (1: the team class's kernel with a single workgroup per sector)
+      std::fill(e->h_class.begin(), e->h_class.end(), kTeamClass);
+  }
+  e->team_w = 0;
+  {
+    // A handful of big sectors (one ROI in the GUI, BASELINE config 1) cannot fill the chip with
+    // one workgroup each: when at most half of the CUs would be busy, every 8-wavefront sector
+    // gets a team as well.  The kernel sizes each sector's team by its own sample count
+    // (kTeamMinSamples per workgroup), the launch clamps the width to what is resident.
+    int n_big = 0;
+    for (int s = 0; s < S; ++s)
+      n_big += e->h_class[(size_t)s] >= kTeamClass - 1;
+    if (n_big > 0 && n_big <= kFewBigSectors && !e->batch_invariant && e->reference_order == 0)
+      for (int s = 0; s < S; ++s)
+        if (e->h_class[(size_t)s] == kTeamClass - 1)
+          e->h_class[(size_t)s] = kTeamClass;
+    int n_team = 0, n0_max = 0;
+    for (int s = 0; s < S; ++s)
+      if (e->h_class[(size_t)s] == kTeamClass) {
+        ++n_team;
+        n0_max = std::max(n0_max, level0_count(e, s));
+      }
+    if (n_team) {
+      int w = force_team >= 1 ? force_team : (n0_max + kTeamMinSamples - 1) / kTeamMinSamples;
+      e->team_w = force_team == 1 ? 1 : std::min(std::max(w, 2), kMaxTeam); // the launch clamps it to what is resident
+      e->team_min_samples = force_team >= 1 ? 0 : kTeamMinSamples;
+      HIPCHK(e->d_team_partials.ensure((size_t)n_team * 2 * (size_t)e->team_w * 32));
+      HIPCHK(e->d_team_arrivals.ensure(2 * (size_t)n_team)); // arrival counters + broken flags
+    }
+  }
+  e->h_order.clear();
+  e->h_order.reserve((size_t)S);
+  for (int c = 0; c < kNumClasses; ++c) {
+    e->class_begin[c] = (int)e->h_order.size();
+    for (int s = 0; s < S; ++s)
+      if (e->h_class[(size_t)s] == c)
+        e->h_order.push_back((uint32_t)s);
+  }
+  e->class_begin[kNumClasses] = (int)e->h_order.size();
+  {
+    int rc = refresh_starved(e);
+    if (rc)
+      return rc;
+  }
+  HIPCHK(e->d_order.ensure((size_t)S));
+  HIPCHK(hipMemcpy(e->d_order.p, e->h_order.data(), (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice));
+  e->classes_dirty = false;
+  return LK_ERROR_NONE;
+}
+
 static int commit_impl(lk_engine *e, bool keep_state) {
   Range range_("lk:commit sectors");
   if (int rc = materialize_host(e)) // (a no-op after any edit: editors fetch the lists first)
@@ -1190,92 +1308,12 @@ static int commit_impl(lk_engine *e, bool keep_state) {
     for (int s = 0; s < S; ++s)
       e->hs[(size_t)s].fresh = false;
   }
-  // size classes -> lanes per sector.  A class whose sectors are too few to fill the chip
-  // (< 2048 wavefronts) and still large per lane is promoted to the next wider group.
-  e->h_class.assign((size_t)S, 0);
-  size_t cnt[kNumClasses] = {0, 0, 0, 0, 0, 0}, tot[kNumClasses] = {0, 0, 0, 0, 0, 0};
-  for (int s = 0; s < S; ++s) {
-    int n0 = level0_count(e, s), c = size_class(n0);
-    e->h_class[(size_t)s] = c;
-    cnt[c]++;
-    tot[c] += (size_t)n0;
-  }
-  for (int c = 0; c + 1 < kTeamClass; ++c) { // (nothing is promoted into the team class)
-    if (!cnt[c] || e->batch_invariant || e->reference_order > 0) // (the group depends on the sector alone)
-      continue;
-    // Wider groups shorten a sector's own critical path and cost lane packing: they pay only
-    // while the narrow grouping leaves SIMDs without a wavefront (fewer wavefronts than the
-    // 1024 SIMDs).  Measured on 19x19-sample sectors (scripts/quick_solve.py, LK_GRID /
-    // LK_FORCE_GROUP): 1024 sectors 0.110 ms in 32-lane groups against 0.092 ms in 64-lane ones,
-    // 2025 sectors 0.122 / 0.123, 4096 sectors 0.166 / 0.188, 8100 sectors 0.240 / 0.324.
-    size_t waves = cnt[c] * (size_t)kGroupOfClass[c] / 64 * (size_t)e->pairs_in_flight; // (the other launches' too)
-    size_t per_lane = tot[c] / cnt[c] / (size_t)kGroupOfClass[c];
-    const bool small_group = kGroupOfClass[c] < 64;
-    const size_t enough = kGroupOfClass[c] == 16 ? 4096 : 1024; // (16-lane groups: 10 000 sectors 0.31 against 0.27 ms)
-    if ((small_group && waves < enough && per_lane >= 4) || (!small_group && waves < 2048 && per_lane >= 32)) {
-      for (int s = 0; s < S; ++s)
-        if (e->h_class[(size_t)s] == c)
-          e->h_class[(size_t)s] = c + 1;
-      cnt[c + 1] += cnt[c];
-      tot[c + 1] += tot[c];
-      cnt[c] = tot[c] = 0;
-    }
-  }
-  if (const char *f = std::getenv("LK_FORCE_GROUP")) { // tuning experiments only
-    int g = std::atoi(f);
-    for (int c = 0; c < kNumClasses; ++c)
-      if (kGroupOfClass[c] == g)
-        std::fill(e->h_class.begin(), e->h_class.end(), c);
-  }
-  int force_team = 0;
-  if (const char *f = std::getenv("LK_FORCE_TEAM")) { // test hook: every sector gets a team of this width
-    force_team = std::atoi(f);
-    if (force_team >= 1) // (1: the team class's kernel with a single workgroup per sector)
-      std::fill(e->h_class.begin(), e->h_class.end(), kTeamClass);
-  }
-  e->team_w = 0;
+  e->S = S;
   {
-    // A handful of big sectors (one ROI in the GUI, BASELINE config 1) cannot fill the chip with
-    // one workgroup each: when at most half of the CUs would be busy, every 8-wavefront sector
-    // gets a team as well.  The kernel sizes each sector's team by its own sample count
-    // (kTeamMinSamples per workgroup), the launch clamps the width to what is resident.
-    int n_big = 0;
-    for (int s = 0; s < S; ++s)
-      n_big += e->h_class[(size_t)s] >= kTeamClass - 1;
-    if (n_big > 0 && n_big <= kFewBigSectors && !e->batch_invariant && e->reference_order == 0)
-      for (int s = 0; s < S; ++s)
-        if (e->h_class[(size_t)s] == kTeamClass - 1)
-          e->h_class[(size_t)s] = kTeamClass;
-    int n_team = 0, n0_max = 0;
-    for (int s = 0; s < S; ++s)
-      if (e->h_class[(size_t)s] == kTeamClass) {
-        ++n_team;
-        n0_max = std::max(n0_max, level0_count(e, s));
-      }
-    if (n_team) {
-      int w = force_team >= 1 ? force_team : (n0_max + kTeamMinSamples - 1) / kTeamMinSamples;
-      e->team_w = force_team == 1 ? 1 : std::min(std::max(w, 2), kMaxTeam); // the launch clamps it to what is resident
-      e->team_min_samples = force_team >= 1 ? 0 : kTeamMinSamples;
-      HIPCHK(e->d_team_partials.ensure((size_t)n_team * 2 * (size_t)e->team_w * 32));
-      HIPCHK(e->d_team_arrivals.ensure(2 * (size_t)n_team)); // arrival counters + broken flags
-    }
-  }
-  e->h_order.clear();
-  e->h_order.reserve((size_t)S);
-  for (int c = 0; c < kNumClasses; ++c) {
-    e->class_begin[c] = (int)e->h_order.size();
-    for (int s = 0; s < S; ++s)
-      if (e->h_class[(size_t)s] == c)
-        e->h_order.push_back((uint32_t)s);
-  }
-  e->class_begin[kNumClasses] = (int)e->h_order.size();
-  {
-    int rc = refresh_starved(e);
+    int rc = classify_sectors(e);
     if (rc)
       return rc;
   }
-  HIPCHK(e->d_order.ensure((size_t)S));
-  HIPCHK(hipMemcpy(e->d_order.p, e->h_order.data(), (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice));
   HIPCHK(e->d_single.ensure(1));
   HIPCHK(e->d_queue.ensure(8 * kNumClasses));
   HIPCHK(hipMemset(e->d_queue.p, 0, 8 * kNumClasses * sizeof(uint32_t))); // (the SAFE pass rewinds its own queue)
@@ -1291,6 +1329,108 @@ static int commit_impl(lk_engine *e, bool keep_state) {
   e->committed = true;
   e->lv_dirty = true;
   e->stats_valid = false;
+  // may the next commit append? (plain sectors only; every per-sector buffer of this commit is S long)
+  e->append_ok = !any_lazy && !e->lists_on_device;
+  return LK_ERROR_NONE;
+}
+
+// lk_commit_sectors, fast path: every sector committed so far is untouched and the new ones are plain rectangles
+// registered behind them - the reference's first-frame loop, resetPolygon(i) then correlate(i), sector after
+// sector (manager_class.cpp:304-460).  Appending costs O(levels) host work, amortised buffer growth and ONE small
+// launch that writes the sector's rectangles, offsets, centre and zeroed sequence state (the values travel in the
+// kernel arguments: no staging, no synchronisation); the full commit would rebuild and re-upload all S sectors,
+// O(S^2) over the loop.
+static const int kMaxAppend = 64; // more new sectors than this: the full commit is cheaper
+static bool can_append(const lk_engine *e) {
+  const int S0 = e->S, S1 = (int)e->hs.size();
+  if (!e->append_ok || S0 <= 0 || S1 <= S0 || S1 - S0 > kMaxAppend || e->recommit_pending || e->lists_on_device ||
+      e->backup_on_device || !e->hs_backup.empty())
+    return false;
+  for (int s = S0; s < S1; ++s) {
+    const HostSector &h = e->hs[(size_t)s];
+    if (!h.set || !h.is_rect || h.lazy != 0 || size_class(h.n0()) >= kTeamClass - 1)
+      return false;
+  }
+  return true;
+}
+static int append_rect_sectors(lk_engine *e) {
+  Range range_("lk:append sectors");
+  const int S0 = e->S, S1 = (int)e->hs.size();
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const lk_config &cfg = e->cfg;
+  const int first = cfg.py_start == 0 ? cfg.py_step : cfg.py_start; // pyramid_class.cpp:299
+  std::vector<int> levels{0};
+  for (int l = first; l <= cfg.py_stop; l += cfg.py_step)
+    levels.push_back(l);
+  // room for the new sectors (geometric growth; the committed part is kept)
+  const size_t keep = (size_t)S0, want = (size_t)S1;
+  HIPCHK(e->d_center.reserve_keep(want, keep));
+  HIPCHK(e->d_guess.reserve_keep(6 * want, 6 * keep));
+  HIPCHK(e->d_last_p.reserve_keep(6 * want, 6 * keep));
+  HIPCHK(e->d_prev_p.reserve_keep(6 * want, 6 * keep));
+  HIPCHK(e->d_last_eval_p.reserve_keep(6 * want, 6 * keep));
+  HIPCHK(e->d_result.reserve_keep(want, keep));
+  HIPCHK(e->d_stats.reserve_keep(4 * want, 4 * keep));
+  for (int l : levels) {
+    HIPCHK(e->d_rect[l].reserve_keep(want, keep));
+    HIPCHK(e->d_off[l].reserve_keep(want + 1, keep + 1));
+  }
+  // (scratch of the solve: contents do not survive a solve)
+  if (e->d_handoff.n < want)
+    HIPCHK(e->d_handoff.ensure(2 * want + 64));
+  if (e->d_mid.n < want * kLkMidWords)
+    HIPCHK(e->d_mid.ensure((2 * want + 64) * kLkMidWords));
+  if (e->d_ill_list.n < want)
+    HIPCHK(e->d_ill_list.ensure(2 * want + 64));
+  if (e->d_order.n < want)
+    HIPCHK(e->d_order.ensure(2 * want + 64));
+  e->h_center.resize(2 * want);
+  e->h_class.resize(want, 0);
+  bool any_starved = false;
+  for (int s = S0; s < S1; ++s) {
+    HostSector &hs = e->hs[(size_t)s];
+    e->h_center[2 * (size_t)s] = hs.cx;
+    e->h_center[2 * (size_t)s + 1] = hs.cy;
+    LkAppendArgs a{};
+    a.sector = s;
+    a.center = make_float2(hs.cx, hs.cy);
+    a.d_center = e->d_center.p;
+    a.d_guess = e->d_guess.p, a.d_last_p = e->d_last_p.p, a.d_prev_p = e->d_prev_p.p, a.d_last_eval_p = e->d_last_eval_p.p;
+    a.d_result = e->d_result.p;
+    a.d_stats = e->d_stats.p;
+    a.n_levels = (int)levels.size();
+    for (size_t li = 0; li < levels.size(); ++li) {
+      const int l = levels[li];
+      // the decimation rule of pyramid_class.cpp:301-322 applied to a full rectangle: see commit_impl
+      const int xs = ceil_shift(hs.x0, l), xe = floor_shift(hs.x1, l);
+      const int ys = ceil_shift(hs.y0, l), ye = floor_shift(hs.y1, l);
+      const int w = std::max(0, xe - xs + 1), h = std::max(0, ye - ys + 1);
+      const int4 rc = make_int4(xs, ys, std::max(w, 1), w * h);
+      e->h_rect[l].push_back(rc);
+      e->h_off[l].push_back(e->h_off[l].back()); // (a rectangle has no list entries)
+      a.rect[li] = rc;
+      a.off_end[li] = e->h_off[l].back();
+      a.d_rect[li] = e->d_rect[l].p;
+      a.d_off[li] = e->d_off[l].p;
+    }
+    const int c = size_class(hs.n0()); // (promotions are a property of the whole batch: classify_sectors)
+    e->h_class[(size_t)s] = c;
+    const int4 top = e->h_rect[cfg.py_stop][(size_t)s];
+    if (top.w <= starved_max(e))
+      e->class_starved[c] = any_starved = true;
+    HIPCHK(lk_launch_append_sector(a, e->stream));
+    hs.fresh = false;
+  }
+  if (any_starved) {
+    if (e->d_finish_list.n < want)
+      HIPCHK(e->d_finish_list.ensure(2 * want + 64));
+    HIPCHK(e->d_finish_count.ensure(kNumClasses));
+  }
+  e->S = S1;
+  e->committed = true;
+  e->classes_dirty = true; // the batch's size-class analysis and launch order: redone by the next batch solve
+  e->lv_dirty = true;
+  e->stats_valid = false;
   return LK_ERROR_NONE;
 }
 
@@ -1298,7 +1438,11 @@ int lk_commit_sectors(lk_engine *e) {
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
   int rc = materialize_host(e);
-  return rc ? rc : commit_impl(e, false);
+  if (rc)
+    return rc;
+  if (can_append(e))
+    return append_rect_sectors(e);
+  return commit_impl(e, false);
 }
 
 // Lagrangian description, CPU-engine semantics (manager_class.cpp:381-419): every sample of
@@ -1597,10 +1741,44 @@ int lk_update_sector(lk_engine *e, int sector, int mode) {
   const float *m = r.resultingParameters;
   const float def_cx = h.cx + m[0], def_cy = e->P > 1 ? h.cy + m[1] : h.cy; // interpolation_class.cpp:3-43
   const float center[2] = {(float)(int)(def_cx + 0.5f), (float)(int)(def_cy + 0.5f)}; // manager_class.cpp:2087-2088
+  const bool was_rect = h.is_rect;
   if (mode == 1)
     translate_one(h, def_cx - h.cx, def_cy - h.cy, h.has_center ? center : nullptr);
   else
     rewarp_one(h, e->cfg.fitting_model, ev, h.has_center ? center : nullptr);
+  // A rectangle that moved by whole pixels is still an implicit rectangle of the same size: its records are
+  // patched in place (O(levels) host work, one small launch; sequence state untouched), so that the reference's
+  // per-sector loop - updatePolygon(i), correlate(i) for every sector (cuda_class.cu:569, manager_class.cpp:449) -
+  // stays O(S).  Anything else (a sector that became a list) rebuilds everything before the next solve.
+  if (was_rect && h.is_rect && e->append_ok && !e->recommit_pending && !e->lists_on_device) {
+    const lk_config &cfg = e->cfg;
+    const int first = cfg.py_start == 0 ? cfg.py_step : cfg.py_start;
+    LkAppendArgs a{};
+    a.sector = sector;
+    a.keep_state = 1;
+    a.center = make_float2(h.cx, h.cy);
+    a.d_center = e->d_center.p;
+    e->h_center[2 * (size_t)sector] = h.cx;
+    e->h_center[2 * (size_t)sector + 1] = h.cy;
+    int li = 0;
+    for (int l = 0; l <= cfg.py_stop; l = (l == 0 ? first : l + cfg.py_step), ++li) {
+      const int xs = ceil_shift(h.x0, l), xe = floor_shift(h.x1, l);
+      const int ys = ceil_shift(h.y0, l), ye = floor_shift(h.y1, l);
+      const int w = std::max(0, xe - xs + 1), hh = std::max(0, ye - ys + 1);
+      const int4 rc = make_int4(xs, ys, std::max(w, 1), w * hh);
+      e->h_rect[l][(size_t)sector] = rc;
+      a.rect[li] = rc;
+      a.d_rect[li] = e->d_rect[l].p;
+      if (l == cfg.py_stop && rc.w <= starved_max(e) && !e->class_starved[e->h_class[(size_t)sector]]) {
+        e->class_starved[e->h_class[(size_t)sector]] = true;
+        HIPCHK(e->d_finish_list.ensure((size_t)std::max<size_t>(e->d_order.n, (size_t)e->S)));
+        HIPCHK(e->d_finish_count.ensure(kNumClasses));
+      }
+    }
+    a.n_levels = li;
+    HIPCHK(lk_launch_append_sector(a, e->stream));
+    return LK_ERROR_NONE;
+  }
   e->recommit_pending = true;
   return LK_ERROR_NONE;
 }
@@ -1892,6 +2070,12 @@ static int stale_iterations(lk_engine *e, lk_result *d_result, int n) {
 }
 
 static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
+  if (e->classes_dirty) { // sectors were appended since the last analysis of the whole domain
+    HIPCHK(hipStreamSynchronize(e->stream)); // (earlier launches may still read the order table)
+    int rc = classify_sectors(e);
+    if (rc)
+      return rc;
+  }
   Range range_("lk:solve");
   if (e->timing)
     HIPCHK(hipEventRecord(e->ev_s0, e->stream));
@@ -1978,7 +2162,7 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
     }
     ++n_launched;
   }
-  if (e->reference_order > 0) {
+  if (e->reference_order > 0 && !e->defer_stale) {
     int rc = stale_iterations(e, d_result, e->S);
     if (rc)
       return rc;
@@ -2036,13 +2220,33 @@ int lk_wait_results(lk_engine *e, lk_result *out) {
 int lk_correlate_all_device(lk_engine *e, const void *d_guesses, void *d_results) {
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
-  if (!d_results)
-    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_correlate_all_device: null result buffer");
   HIPCHK(hipSetDevice(e->cfg.device));
   int rc = refresh_level_views(e);
   if (rc)
     return rc;
-  return launch_all(e, d_guesses ? (const float *)d_guesses : e->d_guess.p, (lk_result *)d_results);
+  return launch_all(e, d_guesses ? (const float *)d_guesses : e->d_guess.p,
+                    d_results ? (lk_result *)d_results : e->d_result.p);
+}
+
+} // extern "C"
+
+int lk_internal_set_defer_stale(lk_engine *e, int on) { // (lk_internal.hpp)
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  e->defer_stale = on != 0;
+  return LK_ERROR_NONE;
+}
+int lk_internal_reference_order(const lk_engine *e) { return e ? e->reference_order : 0; }
+
+extern "C" {
+
+int lk_get_results_device(lk_engine *e, const void **d_records) {
+  if (!e || !d_records)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!e->committed)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_results_device: sectors are not committed");
+  *d_records = e->d_result.p;
+  return LK_ERROR_NONE;
 }
 
 int lk_correlate_all(lk_engine *e, const float *guesses, lk_result *out) {

@@ -8,14 +8,24 @@
 // one-thread-per-device model of ncclCommInitAll - so the collectives rendezvous without
 // ncclGroupStart/End.  No host thread ever waits for another one inside a job, except in the
 // one-GPU rehearsal mode (the same device listed several times), where device-to-device copies
-// and a host barrier stand in for the two collectives.  What can fail on one member alone (device allocations)
-// runs in a job of its own BEFORE the job that issues a collective, so that no member enters a collective the
-// others never reach; the argument checks of the engine calls fail on all members alike.
+// and a host barrier stand in for the two collectives.
+//
+// Failures.  A member that gave up before a collective would leave the others' collective - and rank 0's
+// hipStreamSynchronize behind it - waiting for ever.  So every job is cut into phases: what can fail on one
+// member alone (allocations, a deferred re-commit inside the engine, uploads, the solve launch) comes first, then
+// the members AGREE on the outcome (lk_group::agree: a host rendezvous that hands everybody the first error of
+// the phase), and only if nobody failed does anybody enqueue the collective.  A collective that fails at
+// enqueue on one member is agreed on the same way afterwards: every member then aborts its communicator
+// (ncclCommAbort ends the kernels of the ranks that did enqueue) and the group is broken for good - every
+// later call returns LK_ERROR_DEVICE.  The rehearsal mode's barriers are reached by every member whatever
+// happened before them; the error code travels past them.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -24,6 +34,7 @@
 #include <vector>
 
 #include "../../include/lk_group.h"
+#include "lk_internal.hpp"
 
 namespace {
 
@@ -45,8 +56,11 @@ struct Member {
   float *d_guess = nullptr;   // [cap][6]
   lk_result *d_rec = nullptr; // [cap] this member's block (padded)
   lk_result *d_all = nullptr; // [n][cap] everybody's blocks
+  int *d_stale = nullptr;     // [2] reference-order mode: the group-level stale iteration count, alternating
+  int stale_par = 0;
   size_t cap = 0;
   int first = 0, count = 0;
+  bool device_ok = true; // hipSetDevice of the current job worked
   std::thread th;
 };
 
@@ -77,27 +91,43 @@ struct lk_group {
   std::condition_variable bcv;
   int barrier_count = 0;
   unsigned long long barrier_gen = 0;
+  int agree_rc = 0, agree_result = 0; // first error of the phase being agreed on / what the last agreement returned
+  std::atomic<bool> broken{false};    // a collective failed on some member: the communicators are aborted
+  bool job_collective = false;        // the current job has rendezvous points: every member must run it to the end
   std::string err;
 
   int fail(int code, const std::string &what) {
     err = what;
     return code;
   }
-  void barrier() {
+  void barrier() { (void)agree(0); }
+  // Rendezvous of the member threads that also settles whether the phase before it succeeded everywhere:
+  // every member passes its own code and all of them receive the same answer - the first non-zero code by
+  // rank order of arrival, or 0.  Nobody proceeds into a collective unless the answer is 0.
+  int agree(int rc) {
     std::unique_lock<std::mutex> lock(bmu);
     const unsigned long long g0 = barrier_gen;
+    if (rc && !agree_rc)
+      agree_rc = rc;
     if (++barrier_count == (int)m.size()) {
       barrier_count = 0;
+      agree_result = agree_rc;
+      agree_rc = 0;
       ++barrier_gen;
       bcv.notify_all();
-    } else {
-      bcv.wait(lock, [&] { return barrier_gen != g0; });
+      return agree_result;
     }
+    bcv.wait(lock, [&] { return barrier_gen != g0; });
+    return agree_result;
   }
   // run `f` on every member thread; returns the first error
-  int run(std::function<int(Member &)> f) {
+  // collective = true: the job contains rendezvous points (lk_group::agree) that every member must reach
+  int run(std::function<int(Member &)> f, bool collective = false) {
+    if (broken)
+      return fail(LK_ERROR_DEVICE, "the group is broken: a collective failed earlier (communicators aborted)");
     std::unique_lock<std::mutex> lock(mu);
     job = std::move(f);
+    job_collective = collective;
     std::fill(rc.begin(), rc.end(), 0);
     pending = (int)m.size();
     ++gen;
@@ -124,6 +154,7 @@ void worker(lk_group *g, int rank) {
   unsigned long long seen = 0;
   for (;;) {
     std::function<int(Member &)> f;
+    bool collective = false;
     {
       std::unique_lock<std::mutex> lock(g->mu);
       g->cv_job.wait(lock, [&] { return g->quit || g->gen != seen; });
@@ -131,8 +162,14 @@ void worker(lk_group *g, int rank) {
         return;
       seen = g->gen;
       f = g->job;
+      collective = g->job_collective;
     }
-    int r = hipSetDevice(me.device) == hipSuccess ? f(me) : LK_ERROR_DEVICE;
+    // (a member that cannot even select its device still runs a COLLECTIVE job, with the failure latched, so
+    // that it reaches every rendezvous of the job: see lk_group::agree)
+    me.device_ok = hipSetDevice(me.device) == hipSuccess;
+    int r = (me.device_ok || collective) ? f(me) : LK_ERROR_DEVICE;
+    if (!me.device_ok && !r)
+      r = LK_ERROR_DEVICE;
     {
       std::unique_lock<std::mutex> lock(g->mu);
       g->rc[(size_t)rank] = r;
@@ -183,20 +220,49 @@ int ensure_frame(lk_group *g, Member &me, int slot, size_t bytes) {
   return LK_ERROR_NONE;
 }
 
-// pixels are in rank 0's d_frame[slot]: send them to everybody and build the pyramids
-int distribute_frame(lk_group *g, Member &me, int slot, int rows, int cols) {
+// after a collective failed on some member: end what the others enqueued, refuse everything from now on
+int collective_failed(lk_group *g, Member &me, int rc) {
+  if (me.comm) {
+    (void)ncclCommAbort(me.comm);
+    me.comm = nullptr;
+  }
+  g->broken = true; // (every member writes the same value; read by lk_group::run after the job)
+  return rc;
+}
+
+// Pixels are (being copied) in rank 0's d_frame[slot] - `upload_rc` is what that member's upload returned -:
+// send them to everybody and build the pyramids.
+int distribute_frame(lk_group *g, Member &me, int slot, int rows, int cols, int upload_rc) {
   const size_t bytes = (size_t)rows * (size_t)cols;
+  auto local = [&](int rc) { return me.device_ok ? rc : LK_ERROR_DEVICE; };
+  if (int rc = g->agree(local(upload_rc))) // nobody enters the collective unless every member got this far
+    return rc;
   if (!g->loopback) {
-    GNCCL(ncclBroadcast(me.d_frame[slot], me.d_frame[slot], bytes, ncclUint8, 0, me.comm, me.st));
-  } else if (g->m.size() > 1) {
-    if (me.rank == 0)
-      GHIP(hipStreamSynchronize(me.st));
-    g->barrier(); // rank 0's pixels are there
-    if (me.rank != 0) {
-      GHIP(hipMemcpyAsync(me.d_frame[slot], g->m[0].d_frame[slot], bytes, hipMemcpyDeviceToDevice, me.st));
-      GHIP(hipStreamSynchronize(me.st));
+    int rc = LK_ERROR_NONE;
+    const ncclResult_t ne = ncclBroadcast(me.d_frame[slot], me.d_frame[slot], bytes, ncclUint8, 0, me.comm, me.st);
+    if (ne != ncclSuccess) {
+      g->msg[(size_t)me.rank] = std::string("ncclBroadcast: ") + ncclGetErrorString(ne);
+      rc = LK_ERROR_DEVICE;
     }
-    g->barrier(); // nobody reads rank 0's buffer any more
+    if (int all = g->agree(rc))
+      return collective_failed(g, me, all);
+  } else if (g->m.size() > 1) {
+    int rc = LK_ERROR_NONE;
+    auto hip = [&](hipError_t he, const char *what) {
+      if (he != hipSuccess && !rc) {
+        g->msg[(size_t)me.rank] = std::string(what) + ": " + hipGetErrorString(he);
+        rc = LK_ERROR_DEVICE;
+      }
+    };
+    if (me.rank == 0)
+      hip(hipStreamSynchronize(me.st), "hipStreamSynchronize");
+    rc = g->agree(rc); // rank 0's pixels are there (or everybody knows they are not)
+    if (!rc && me.rank != 0) {
+      hip(hipMemcpyAsync(me.d_frame[slot], g->m[0].d_frame[slot], bytes, hipMemcpyDeviceToDevice, me.st), "hipMemcpyAsync");
+      hip(hipStreamSynchronize(me.st), "hipStreamSynchronize");
+    }
+    if (int all = g->agree(rc)) // nobody reads rank 0's buffer any more
+      return all;
   }
   if (slot == LK_IMG_NXT) // the engine fills that slot on its own next-frame stream: the pixels must have arrived
     GHIP(hipStreamSynchronize(me.st));
@@ -221,8 +287,20 @@ int lk_group_create(const lk_config *cfg, int n_devices, const int *devices, lk_
   g->rc.assign((size_t)n_devices, 0);
   g->msg.assign((size_t)n_devices, std::string());
   std::vector<int> devs((size_t)n_devices);
+  // LK_GROUP_DEVICES=0,0,0 (rehearsal hook, only when the caller names no devices - HipCudaClass::set_deviceCount):
+  // the device list, e.g. one GPU three times = the loopback transport on a one-GPU box
+  std::vector<int> env_devs;
+  if (!devices)
+    if (const char *f = std::getenv("LK_GROUP_DEVICES"))
+      for (const char *q = f; *q;) {
+        env_devs.push_back(std::atoi(q));
+        while (*q && *q != ',')
+          ++q;
+        if (*q == ',')
+          ++q;
+      }
   for (int r = 0; r < n_devices; ++r) {
-    devs[(size_t)r] = devices ? devices[r] : r;
+    devs[(size_t)r] = devices ? devices[r] : ((size_t)r < env_devs.size() ? env_devs[(size_t)r] : r);
     if (devs[(size_t)r] < 0 || devs[(size_t)r] >= ndev) {
       delete g;
       return LK_ERROR_DEVICE;
@@ -239,7 +317,7 @@ int lk_group_create(const lk_config *cfg, int n_devices, const int *devices, lk_
     c.device = me.device;
     ok = lk_create(&c, &me.e) == LK_ERROR_NONE && hipSetDevice(me.device) == hipSuccess &&
          hipStreamCreateWithFlags(&me.st, hipStreamNonBlocking) == hipSuccess &&
-         lk_set_stream(me.e, me.st) == LK_ERROR_NONE;
+         lk_set_stream(me.e, me.st) == LK_ERROR_NONE && lk_internal_set_defer_stale(me.e, 1) == LK_ERROR_NONE;
   }
   if (ok && !g->loopback) {
     std::vector<ncclComm_t> comms((size_t)n_devices);
@@ -277,7 +355,7 @@ void lk_group_destroy(lk_group *g) {
     for (uint8_t *p : me.d_frame)
       if (p)
         (void)hipFree(p);
-    for (void *p : {(void *)me.d_guess, (void *)me.d_rec, (void *)me.d_all})
+    for (void *p : {(void *)me.d_guess, (void *)me.d_rec, (void *)me.d_all, (void *)me.d_stale})
       if (p)
         (void)hipFree(p);
     if (me.e)
@@ -290,6 +368,12 @@ void lk_group_destroy(lk_group *g) {
 
 const char *lk_group_last_error_string(const lk_group *g) { return g ? g->err.c_str() : "null group"; }
 int lk_group_size(const lk_group *g) { return g ? (int)g->m.size() : 0; }
+int lk_group_comm_ranks(const lk_group *g) {
+  if (!g || g->m.empty() || !g->m[0].comm)
+    return 0; // rehearsal transport (one device listed several times): no RCCL communicator
+  int n = 0;
+  return ncclCommCount(g->m[0].comm, &n) == ncclSuccess ? n : -1;
+}
 
 int lk_group_engine(lk_group *g, int rank, lk_engine **e) {
   if (!g || !e || rank < 0 || rank >= (int)g->m.size())
@@ -330,11 +414,17 @@ static int set_image_any(lk_group *g, int slot, const void *src, bool on_device0
     if (int rc = g->run([=](Member &me) -> int { return ensure_frame(g, me, slot, bytes); }))
       return rc;
   return g->run([=](Member &me) -> int {
-    if (me.rank == 0)
-      GHIP(hipMemcpy2DAsync(me.d_frame[slot], (size_t)cols, src, (size_t)step, (size_t)cols, (size_t)rows,
-                            on_device0 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, me.st));
-    return distribute_frame(g, me, slot, rows, cols);
-  });
+    int up = LK_ERROR_NONE;
+    if (me.rank == 0 && me.device_ok) {
+      const hipError_t he = hipMemcpy2DAsync(me.d_frame[slot], (size_t)cols, src, (size_t)step, (size_t)cols, (size_t)rows,
+                                             on_device0 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, me.st);
+      if (he != hipSuccess) {
+        g->msg[(size_t)me.rank] = std::string("hipMemcpy2DAsync: ") + hipGetErrorString(he);
+        up = LK_ERROR_DEVICE;
+      }
+    }
+    return distribute_frame(g, me, slot, rows, cols, up);
+  }, true);
 }
 int lk_group_set_image(lk_group *g, int slot, const uint8_t *host_pixels, int rows, int cols, int step) {
   return set_image_any(g, slot, host_pixels, false, rows, cols, step);
@@ -480,20 +570,59 @@ int lk_group_correlate_all(lk_group *g, const float *guesses, lk_result *out) {
   const int n = (int)g->m.size();
   const size_t block = (size_t)g->cap * sizeof(lk_result);
   return g->run([=](Member &me) -> int {
-    if (guesses)
-      GHIP(hipMemcpyAsync(me.d_guess, guesses + 6 * (size_t)me.first, 6 * (size_t)me.count * sizeof(float),
-                          hipMemcpyHostToDevice, me.st));
-    GLK(lk_correlate_all_device(me.e, guesses ? me.d_guess : nullptr, me.d_rec));
+    // phase 1 - what can fail on this member alone: the guess upload, the engine's deferred re-commit /
+    // allocations, the solve launches.  The records go to the ENGINE's own buffer: lk_update_sector
+    // (HipCudaClass::updatePolygon) moves a sector by the engine's record of it.
+    const void *d_own = nullptr;
+    int rc = [&]() -> int {
+      if (!me.device_ok)
+        return LK_ERROR_DEVICE;
+      if (guesses)
+        GHIP(hipMemcpyAsync(me.d_guess, guesses + 6 * (size_t)me.first, 6 * (size_t)me.count * sizeof(float),
+                            hipMemcpyHostToDevice, me.st));
+      GLK(lk_correlate_all_device(me.e, guesses ? me.d_guess : nullptr, nullptr));
+      GLK(lk_get_results_device(me.e, &d_own));
+      GHIP(hipMemcpyAsync(me.d_rec, d_own, (size_t)me.count * sizeof(lk_result), hipMemcpyDeviceToDevice, me.st)); // (the padded all-gather block)
+      return LK_ERROR_NONE;
+    }();
+    if (int all = g->agree(rc)) // nobody enqueues the all-gather unless every member's solve is on its way
+      return rc ? rc : all;
+    // phase 2 - the exchange
     if (!g->loopback) {
-      GNCCL(ncclAllGather(me.d_rec, me.d_all, block, ncclUint8, me.comm, me.st));
+      const ncclResult_t ne = ncclAllGather(me.d_rec, me.d_all, block, ncclUint8, me.comm, me.st);
+      if (ne != ncclSuccess) {
+        g->msg[(size_t)me.rank] = std::string("ncclAllGather: ") + ncclGetErrorString(ne);
+        rc = LK_ERROR_DEVICE;
+      }
+      if (int all = g->agree(rc))
+        return collective_failed(g, me, rc ? rc : all);
     } else {
-      GHIP(hipStreamSynchronize(me.st));
-      g->barrier(); // every block is final
-      for (int q = 0; q < n; ++q)
-        GHIP(hipMemcpyAsync((char *)g->m[(size_t)q].d_all + (size_t)me.rank * block, me.d_rec, block,
-                            hipMemcpyDeviceToDevice, me.st));
-      GHIP(hipStreamSynchronize(me.st));
-      g->barrier(); // everybody's d_all is complete
+      auto hip = [&](hipError_t he, const char *what) {
+        if (he != hipSuccess && !rc) {
+          g->msg[(size_t)me.rank] = std::string(what) + ": " + hipGetErrorString(he);
+          rc = LK_ERROR_DEVICE;
+        }
+      };
+      hip(hipStreamSynchronize(me.st), "hipStreamSynchronize");
+      rc = g->agree(rc); // every block is final (or everybody knows one is not)
+      if (!rc) {
+        for (int q = 0; q < n; ++q)
+          hip(hipMemcpyAsync((char *)g->m[(size_t)q].d_all + (size_t)me.rank * block, me.d_rec, block,
+                             hipMemcpyDeviceToDevice, me.st), "hipMemcpyAsync");
+        hip(hipStreamSynchronize(me.st), "hipStreamSynchronize");
+      }
+      if (int all = g->agree(rc)) // everybody's d_all is complete
+        return rc ? rc : all;
+    }
+    // phase 3 - reference-order mode: the stale iteration counts, over the gathered records in global sector
+    // order with the group's own carry (every member resolves its copy; all copies end up identical)
+    if (lk_internal_reference_order(me.e) > 0) {
+      if (!me.d_stale) {
+        GHIP(hipMalloc((void **)&me.d_stale, 2 * sizeof(int)));
+        GHIP(hipMemsetAsync(me.d_stale, 0, 2 * sizeof(int), me.st));
+      }
+      GHIP(lk_launch_stale_iterations_blocks(me.d_all, g->S, n, g->cap, me.d_stale + me.stale_par, me.d_stale + (me.stale_par ^ 1), me.st));
+      me.stale_par ^= 1;
     }
     if (out && me.rank == 0) { // global sector order: block r starts at rank r's first sector
       for (int q = 0; q < n; ++q) {
@@ -505,7 +634,7 @@ int lk_group_correlate_all(lk_group *g, const float *guesses, lk_result *out) {
       GHIP(hipStreamSynchronize(me.st));
     }
     return LK_ERROR_NONE;
-  });
+  }, true);
 }
 
 int lk_group_adjust_initial_guess(lk_group *g, int frame, int constant_velocity, const float *global_guess,

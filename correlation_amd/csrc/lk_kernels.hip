@@ -37,6 +37,7 @@
 // (the bicubic coefficient build, see bicubic_sample) or where only the summation order
 // already differs from the reference (the A/b/chi accumulators).
 #include "lk_device.hpp"
+#include "lk_internal.hpp"
 
 #include <float.h>
 #include <stdlib.h>
@@ -814,6 +815,246 @@ __device__ __forceinline__ bool evaluate_ordered(const LevelCtx &c, const float 
 }
 
 // ------------------------------------------------------------------------------------
+// Reference-order evaluation of the FOUR sectors of a wavefront at once, lanes dealt by need.
+//
+// With one 16-lane row per sector (evaluate_ordered<GROUP = 16>) a step of the wavefront costs as many
+// trips as its largest sector needs, whatever the other rows are doing: a row whose sector is finished, or
+// sits at a coarse pyramid level with a handful of samples, idles through the trips of a row at level 0 -
+// and the stragglers of a launch (config 2: up to 29 evaluations where the median is 12, nearly all of them
+// at levels 2 and 1) keep three idle rows waiting.  Measured (profiles/r03_reforder_before_*): the launch
+// lasts 573 us while the median SIMD is done after 308.
+//
+// Here the unit of work is a SLOT = 16 consecutive samples of one sector, and every trip deals its four
+// 16-lane tile rows to the sectors that still have slots left, most remaining first (one row each while four
+// sectors are busy; two or four rows for a sector whose neighbours have run out).  Who FORMS a product does
+// not matter to the bits; who ADDS it does not either, as long as every sum of a sector sees its products in
+// sample order - so the owner lanes stay where they were (the sector's home row: lane v owns sums v and
+// v + 16) and walk the tile rows their sector got in this trip, in ascending order = sample order.  A trip
+// is: slot table (scalar) -> the lanes of a tile row fetch that sector's context from LDS if it changed ->
+// products -> LDS tile [sum][64 samples] -> the home rows add.  A step now costs
+// ceil(sum over the busy sectors of ceil(n / 16) / 4) trips, so the rows need no level alignment and no
+// common fetch any more: every sector runs at its own pace.
+// ------------------------------------------------------------------------------------
+struct OrdCtx { // one sector's evaluation context, published by its home row (24 words)
+  float p[6], cx, cy;
+  int rx, ry, rw, n;
+  int rh, urows, ucols, drows;
+  int dcols;
+  uint32_t und_lo, und_hi, def_lo;
+  uint32_t def_hi, xy_lo, xy_hi;
+  float inv_rh;
+};
+static_assert(sizeof(OrdCtx) == 96, "six 128-bit words");
+constexpr int kFlatStride = kWave + 4; // tile row: 64 samples + 4 floats (the 128-bit reads of neighbouring owner lanes hit different banks)
+template <int N> constexpr int flat_tile_floats() { return N * kFlatStride; }
+
+template <int MODEL, int INTERP, bool CHUNKED>
+__device__ __forceinline__ bool evaluate_ordered_flat(const LevelCtx &c, const float (&p)[6], Sums<n_params(MODEL)> &S,
+                                                      float *tile, OrdCtx *ctx, int threads) {
+  constexpr int P = n_params(MODEL);
+  using SumsT = Sums<P>;
+  constexpr int N = SumsT::N, STR = kFlatStride;
+  constexpr bool TWO = N > 16; // a home row owns up to 32 sums: v and v + 16
+  const int lane = (int)threadIdx.x & (kWave - 1), g = lane & 15, row = lane >> 4;
+  // publish this row's sector (every lane of the row holds the same values)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (the previous evaluation's reads of ctx / tile are done)
+  if (g == 0) {
+    OrdCtx o;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      o.p[i] = p[i];
+    o.cx = c.cx, o.cy = c.cy;
+    o.rx = c.rx, o.ry = c.ry, o.rw = c.rw, o.n = c.n;
+    o.rh = c.rw > 0 ? c.n / c.rw : 1;
+    o.urows = c.urows, o.ucols = c.ucols, o.drows = c.drows, o.dcols = c.dcols;
+    const unsigned long long ub = (unsigned long long)(uintptr_t)c.und, db = (unsigned long long)(uintptr_t)c.def,
+                             xb = (unsigned long long)(uintptr_t)c.xy;
+    o.und_lo = (uint32_t)ub, o.und_hi = (uint32_t)(ub >> 32), o.def_lo = (uint32_t)db, o.def_hi = (uint32_t)(db >> 32);
+    o.xy_lo = (uint32_t)xb, o.xy_hi = (uint32_t)(xb >> 32);
+    o.inv_rh = 1.f / (float)o.rh;
+    const float4 *src = reinterpret_cast<const float4 *>(&o);
+    float4 *dst = reinterpret_cast<float4 *>(ctx + row);
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      dst[i] = src[i];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // slots left per sector (wavefront-uniform: scalar registers)
+  int rem[4], used[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    rem[r] = (__builtin_amdgcn_readlane(c.n, 16 * r) + 15) >> 4;
+    used[r] = 0;
+  }
+  // owner state of my sector (home row): running chunk sums and totals of sums v0 (and v1)
+  const int v0 = g < N ? g : 0, v1 = (TWO && g + 16 < N) ? g + 16 : 0; // (idle lanes shadow sum 0)
+  float acc0 = 0.f, acc1 = 0.f, tot0 = 0.f, tot1 = 0.f;
+  const int T = CHUNKED ? (threads < 1 ? 1 : threads) : 1;
+  const int cq = c.n / T, cr = c.n - cq * T; // thread chunks of the reference: chunk t has n/T + (t < n%T) samples
+  int t_idx = 0, next_b = cq + (cr > 0 ? 1 : 0), kpos = 0;
+  unsigned bad_sectors = 0u; // bit r: a sample of sector r left the image
+  // the context of the sector my tile row works for (reloaded only when the deal changes)
+  OrdCtx e{};
+  int cur = -1;
+  while ((rem[0] | rem[1] | rem[2] | rem[3]) != 0) {
+    // deal the four tile rows: most slots left first (ties: the lower sector)
+    int sec[4], k0[4];
+    unsigned rows_of[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int tr = 0; tr < 4; ++tr) {
+      int best = 0, bv = rem[0];
+#pragma unroll
+      for (int r = 1; r < 4; ++r)
+        if (rem[r] > bv)
+          bv = rem[r], best = r;
+      sec[tr] = bv > 0 ? best : -1;
+      k0[tr] = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (bv > 0 && best == r) {
+          k0[tr] = used[r] << 4;
+          ++used[r];
+          --rem[r];
+          rows_of[r] |= 1u << tr;
+        }
+    }
+    const int my_sec = row == 0 ? sec[0] : row == 1 ? sec[1] : row == 2 ? sec[2] : sec[3];
+    const int my_k0 = row == 0 ? k0[0] : row == 1 ? k0[1] : row == 2 ? k0[2] : k0[3];
+    if (__any(my_sec >= 0 && my_sec != cur)) {
+      const int want = my_sec >= 0 ? my_sec : (cur >= 0 ? cur : 0);
+      const float4 *src = reinterpret_cast<const float4 *>(ctx + want);
+      float4 *dst = reinterpret_cast<float4 *>(&e);
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        dst[i] = src[i];
+      cur = want;
+    }
+    const int k = my_k0 + g;
+    float t[N];
+#pragma unroll
+    for (int v = 0; v < N; ++v)
+      t[v] = 0.f;
+    bool bad = false;
+    if (my_sec >= 0 && k < e.n) {
+      f32x2 q;
+      if (e.rw > 0) { // x outer, y inner: k -> (column, row) of the rectangle
+        const int rh = e.rh;
+        int col = (int)((float)k * e.inv_rh); // k / rh to within one unit below 2^23 samples, two below 2^25
+        int rr = k - col * rh;
+#pragma unroll
+        for (int fix = 0; fix < 2; ++fix) {
+          const int lo = rr < 0 ? 1 : 0, hi = rr >= rh ? 1 : 0;
+          rr += (lo - hi) * rh;
+          col += hi - lo;
+        }
+        q.x = (float)(e.rx + col);
+        q.y = (float)(e.ry + rr);
+      } else {
+        q = ((gptr<f32x2>)(uintptr_t)(((unsigned long long)e.xy_hi << 32) | e.xy_lo))[k];
+      }
+      gptr<uint8_t> und = (gptr<uint8_t>)(uintptr_t)(((unsigned long long)e.und_hi << 32) | e.und_lo);
+      gptr<uint8_t> def = (gptr<uint8_t>)(uintptr_t)(((unsigned long long)e.def_hi << 32) | e.def_lo);
+      float xd, yd, dx = 0.f, dy = 0.f;
+      Warp<MODEL>::apply(q.x, q.y, e.cx, e.cy, e.p, xd, yd, dx, dy);
+      int uix = (int)(q.x + 0.5f), uiy = (int)(q.y + 0.5f);
+      uix = min(max(uix, 0), e.ucols - 1);
+      uiy = min(max(uiy, 0), e.urows - 1);
+      const float und_w = (float)und[(size_t)uiy * (size_t)e.ucols + (size_t)uix];
+      float W, Wx, Wy;
+      if (!sample_def<INTERP>(def, e.drows, e.dcols, xd, yd, W, Wx, Wy)) {
+        bad = true; // (the sums of an evaluation that hit the error are never used)
+      } else {
+        const float V = und_w - W;
+        float H[P];
+        Warp<MODEL>::jac(Wx, Wy, dx, dy, H);
+        int idx = 0;
+#pragma unroll
+        for (int p1 = 0; p1 < P; ++p1)
+#pragma unroll
+          for (int p2 = p1; p2 < P; ++p2)
+            t[idx++] = H[p1] * H[p2]; // rounded product; the rounded add follows below
+#pragma unroll
+        for (int p1 = 0; p1 < P; ++p1)
+          t[SumsT::NA + p1] = H[p1] * V;
+        t[N - 1] = V * V;
+      }
+    }
+    {
+      const unsigned long long bm = __ballot(bad);
+#pragma unroll
+      for (int tr = 0; tr < 4; ++tr)
+        if (sec[tr] >= 0 && ((bm >> (16 * tr)) & 0xffffull) != 0ull)
+          bad_sectors |= 1u << sec[tr];
+    }
+    // transpose: my product of sum v -> tile[v][lane]
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the previous trip's reads are done
+#pragma unroll
+    for (int v = 0; v < N; ++v)
+      tile[v * STR + lane] = t[v];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // the home rows add what their sectors got in this trip, tile rows in ascending order = sample order
+    unsigned mine = row == 0 ? rows_of[0] : row == 1 ? rows_of[1] : row == 2 ? rows_of[2] : rows_of[3];
+    const int most = max(max(__builtin_popcount(rows_of[0]), __builtin_popcount(rows_of[1])),
+                         max(__builtin_popcount(rows_of[2]), __builtin_popcount(rows_of[3])));
+    for (int j = 0; j < most; ++j) {
+      if (mine != 0u) {
+        const int tr = __builtin_ctz(mine);
+        mine &= mine - 1u;
+        const float *r0 = tile + v0 * STR + 16 * tr, *r1 = tile + v1 * STR + 16 * tr;
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+          const float4 a4 = *reinterpret_cast<const float4 *>(r0 + 4 * j4);
+          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if constexpr (TWO)
+            b4 = *reinterpret_cast<const float4 *>(r1 + 4 * j4);
+          const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            if (CHUNKED && kpos + 4 * j4 + jj == next_b) { // a thread chunk ends before this sample (:253-275)
+              tot0 += acc0;
+              acc0 = 0.f;
+              if constexpr (TWO) {
+                tot1 += acc1;
+                acc1 = 0.f;
+              }
+              ++t_idx;
+              next_b += cq + (t_idx < cr ? 1 : 0);
+            }
+            acc0 += av[jj];
+            if constexpr (TWO)
+              acc1 += bv[jj];
+          }
+        }
+        kpos += 16;
+      }
+    }
+  }
+  tot0 += acc0; // the last chunk (T == 1: 0 + acc)
+  if constexpr (TWO)
+    tot1 += acc1;
+  // totals back to every lane of the home row
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  float *back = tile + row * 32;
+  if (g < N)
+    back[g] = tot0;
+  if constexpr (TWO)
+    if (g + 16 < N)
+      back[g + 16] = tot1;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int v = 0; v < N; ++v)
+    S.v[v] = back[v];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (the next evaluation overwrites the tile)
+  return ((bad_sectors >> row) & 1u) != 0u;
+}
+
+// ------------------------------------------------------------------------------------
 // the damped normal-equation solve (compute_model_parameters + solve,
 // correlation_class.cpp:642-768)
 // ------------------------------------------------------------------------------------
@@ -1403,23 +1644,28 @@ template <bool IN_LDS> struct ColdStore {
 // 8 words per workgroup: start, end, cycles inside evaluate<>, steps, HW_ID, XCC_ID, first sector, -
 __device__ unsigned long long g_lk_trace[8 * 16384];
 #endif
-template <int MODEL, int INTERP, int GROUP, int THREADS, bool SAFE>
+// REF: the reference-order instances (lk_set_reference_order) - SAFE, one wavefront per workgroup, a 16-lane row
+// (four sectors per wavefront, lanes dealt by need: evaluate_ordered_flat) or a wavefront per sector.
+template <int MODEL, int INTERP, int GROUP, int THREADS, bool SAFE, bool REF = false>
 __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : THREADS == 512 ? LK_MIN_WAVES_512 : 1)) lk_solve_kernel(LkSolveArgs a) {
+  static_assert(!REF || (SAFE && THREADS == kWave && (GROUP == 16 || GROUP == kWave)), "reference-order instances");
   constexpr int P = n_params(MODEL);
   using SumsT = Sums<P>;
   constexpr bool COLD_IN_LDS = GROUP > 1 && GROUP <= kWave;
   constexpr bool STARVED = GROUP == 1; // one lane per sector: solves only the starved top levels
   // the 16-lane SAFE instance doubles as the finisher of that kernel's stragglers (a.finisher)
-  const bool finisher = SAFE && GROUP == 16 && a.finisher != 0;
-  // reference-order mode (lk_set_reference_order): the SAFE 16- and 64-lane instances solve every
-  // level with evaluate_ordered + the restated QR - sums, steps and records bit-identical to the
-  // CPU engine with number_of_threads = a.reference_order
-  constexpr bool ORD = SAFE && THREADS == kWave && (GROUP == 16 || GROUP == kWave);
-  const bool ordered_all = ORD && a.reference_order > 0;
+  const bool finisher = !REF && SAFE && GROUP == 16 && a.finisher != 0;
+  // reference-order mode (lk_set_reference_order): the REF instances solve every level with the ordered sums
+  // + the restated QR - sums, steps and records bit-identical to the CPU engine with
+  // number_of_threads = a.reference_order
+  constexpr bool ORD = REF;
+  constexpr bool ordered_all = REF;
   const bool starved = STARVED || finisher || ordered_all;
   constexpr int RED_WORDS = GROUP > kWave ? (THREADS / kWave) * (SumsT::N + 1) + 1 : 1;
   __shared__ float lds[RED_WORDS];
-  __shared__ __attribute__((aligned(16))) float ord_lds[ORD ? ord_floats<SumsT::N, ORD ? GROUP : 16>() : 4];
+  constexpr bool FLAT = REF && GROUP == 16; // four sectors per wavefront, lanes dealt by need
+  __shared__ __attribute__((aligned(16))) float ord_lds[FLAT ? flat_tile_floats<SumsT::N>() : ORD ? ord_floats<SumsT::N, ORD ? GROUP : 16>() : 4];
+  __shared__ __attribute__((aligned(16))) OrdCtx ord_ctx[FLAT ? 4 : 1];
   // The sums of the last ACCEPTED evaluation stay with the sector (small groups: behind its cold state in LDS; one
   // lane per sector: in registers).  A rejected trip continues from the last good parameters with a larger lambda;
   // the reference evaluates there once more (correlation_class.cpp:441-499) and gets, of course, the sums it had
@@ -1646,7 +1892,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : THREA
     if constexpr (GROUP > 1 && GROUP < kWave) {
       // aligned wavefronts fetch together: a group that finished early waits for its
       // neighbours, so that the next batch of sectors starts the pyramid in step
-      if (a.align && a.persistent)
+      if (a.align && a.persistent && !FLAT) // (FLAT: lanes are dealt by need, every sector runs at its own pace)
         may_fetch = __ballot(phase < PH_FETCH) == 0ull;
     }
     if constexpr (GROUP == 16) {
@@ -1845,7 +2091,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : THREA
       // level's price for every step.  A group that is ahead (at a finer level than the
       // coarsest one still being solved in its wavefront) skips steps until the others have
       // caught up; then all of them walk the expensive fine level together.
-      if (a.align) {
+      if (a.align && !FLAT) {
         int wave_level = -1;
         for (int L = a.py_stop; L >= a.py_start && wave_level < 0; L -= a.py_step)
           if (__ballot(active && cur_level == L) != 0ull)
@@ -1861,10 +2107,12 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : THREA
     const unsigned long long tr_e0 = __builtin_amdgcn_s_memtime();
 #endif
     bool err;
-    if constexpr (ORD) {
-      err = !ordered_all ? evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds, &team, wide, finisher, GROUP == 16 ? width : 0)
-            : a.reference_order > 1 ? evaluate_ordered<MODEL, INTERP, GROUP, true>(ce, p, S, ord_lds, a.reference_order)
-                                    : evaluate_ordered<MODEL, INTERP, GROUP, false>(ce, p, S, ord_lds, 1);
+    if constexpr (FLAT) {
+      err = a.reference_order > 1 ? evaluate_ordered_flat<MODEL, INTERP, true>(ce, p, S, ord_lds, ord_ctx, a.reference_order)
+                                  : evaluate_ordered_flat<MODEL, INTERP, false>(ce, p, S, ord_lds, ord_ctx, 1);
+    } else if constexpr (ORD) {
+      err = a.reference_order > 1 ? evaluate_ordered<MODEL, INTERP, GROUP, true>(ce, p, S, ord_lds, a.reference_order)
+                                  : evaluate_ordered<MODEL, INTERP, GROUP, false>(ce, p, S, ord_lds, 1);
     } else {
       err = evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds, &team, wide, finisher, GROUP == 16 ? width : 0);
     }
@@ -2113,7 +2361,8 @@ __global__ void __launch_bounds__(256) lk_eval_kernel(LkEvalArgs a) {
   using SumsT = Sums<P>;
   __shared__ float lds[4 * (SumsT::N + 1)];
   constexpr int OG = GROUP == 16 ? 16 : kWave; // lane group of the reference-order evaluation
-  __shared__ __attribute__((aligned(16))) float ord_lds[ord_floats<SumsT::N, OG>()];
+  __shared__ __attribute__((aligned(16))) float ord_lds[OG == 16 ? flat_tile_floats<SumsT::N>() : ord_floats<SumsT::N, OG>()];
+  __shared__ __attribute__((aligned(16))) OrdCtx ord_ctx[4];
   if (a.ref_threads > 0 && (int)threadIdx.x >= kWave)
     return; // reference order: one wavefront (its first row or all of it) owns the sector
   const LkLevelView lv = a.lv[a.level];
@@ -2144,10 +2393,15 @@ __global__ void __launch_bounds__(256) lk_eval_kernel(LkEvalArgs a) {
   SumsT S;
   bool err;
   if (a.ref_threads > 0) {
-    if (OG == 16 && (int)threadIdx.x >= 16)
-      c.n = 0;
-    err = a.ref_threads > 1 ? evaluate_ordered<MODEL, INTERP, OG, true>(c, p, S, ord_lds, a.ref_threads)
-                            : evaluate_ordered<MODEL, INTERP, OG, false>(c, p, S, ord_lds, 1);
+    if constexpr (OG == 16) { // the solve kernel's small-sector path: the sector in row 0, the other rows' lanes lent to it
+      if ((int)threadIdx.x >= 16)
+        c.n = 0;
+      err = a.ref_threads > 1 ? evaluate_ordered_flat<MODEL, INTERP, true>(c, p, S, ord_lds, ord_ctx, a.ref_threads)
+                              : evaluate_ordered_flat<MODEL, INTERP, false>(c, p, S, ord_lds, ord_ctx, 1);
+    } else {
+      err = a.ref_threads > 1 ? evaluate_ordered<MODEL, INTERP, OG, true>(c, p, S, ord_lds, a.ref_threads)
+                              : evaluate_ordered<MODEL, INTERP, OG, false>(c, p, S, ord_lds, 1);
+    }
   } else {
     err = evaluate<MODEL, INTERP, GROUP, 256>(c, p, S, lds);
   }
@@ -2778,6 +3032,37 @@ __global__ void lk_stale_iterations_kernel(lk_result *r, int n, const int *carry
     *carry_out = v;
 }
 
+// The same over the gathered records of a group (lk_group.cpp): n_ranks padded blocks of `cap` records, block q
+// holding the sectors [q*S/G, (q+1)*S/G) - resolved in GLOBAL sector order, so a shard's leading marked records
+// take the count the shard before it left behind.
+__device__ __forceinline__ size_t stale_block_pos(int s, int n, int n_ranks, int cap) {
+  int q = (int)(((long long)s * n_ranks + n_ranks - 1) / n); // first guess, then the exact owner: first_q <= s < first_{q+1}
+  q = q < 0 ? 0 : (q >= n_ranks ? n_ranks - 1 : q);
+  while (q > 0 && (int)((long long)n * q / n_ranks) > s)
+    --q;
+  while (q + 1 < n_ranks && (int)((long long)n * (q + 1) / n_ranks) <= s)
+    ++q;
+  return (size_t)q * (size_t)cap + (size_t)(s - (int)((long long)n * q / n_ranks));
+}
+__global__ void lk_stale_iterations_blocks_kernel(lk_result *r, int n, int n_ranks, int cap, const int *carry_in, int *carry_out) {
+  const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (s >= n)
+    return;
+  int *it = &r[stale_block_pos(s, n, n_ranks, cap)].iterations;
+  int v = __hip_atomic_load(it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (v == kStaleIterations) {
+    int t = s - 1;
+    while (t >= 0 && (v = __hip_atomic_load(&r[stale_block_pos(t, n, n_ranks, cap)].iterations, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT)) == kStaleIterations)
+      --t;
+    if (t < 0)
+      v = *carry_in;
+    __hip_atomic_store(it, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (s == n - 1)
+    *carry_out = v;
+}
+
 // ---- the sequential float mean of an INTEGER sample list, evaluated in parallel, bit for bit ----
 // pyramid_class.cpp:325-340 adds the coordinates into one running float per axis, in list order.
 // For a 4.2 M-sample blob that chain is 4.2 M dependent additions (tens of ms for one wavefront).
@@ -3170,6 +3455,42 @@ hipError_t lk_launch_stale_iterations(lk_result *r, int n, const int *carry_in, 
   return hipGetLastError();
 }
 
+__global__ void lk_append_sector_kernel(LkAppendArgs a) {
+  const int t = (int)threadIdx.x, s = a.sector;
+  if (t < a.n_levels) {
+    a.d_rect[t][s] = a.rect[t];
+    if (!a.keep_state)
+      a.d_off[t][s + 1] = a.off_end[t];
+  }
+  if (t == 0)
+    a.d_center[s] = a.center;
+  if (a.keep_state)
+    return;
+  if (t < 6) {
+    a.d_guess[(size_t)s * 6 + t] = 0.f;
+    a.d_last_p[(size_t)s * 6 + t] = 0.f;
+    a.d_prev_p[(size_t)s * 6 + t] = 0.f;
+    a.d_last_eval_p[(size_t)s * 6 + t] = 0.f;
+  }
+  if (t < 4)
+    a.d_stats[(size_t)s * 4 + t] = 0u;
+  if (t < (int)(sizeof(lk_result) / 4))
+    reinterpret_cast<uint32_t *>(a.d_result + s)[t] = 0u;
+}
+hipError_t lk_launch_append_sector(const LkAppendArgs &a, hipStream_t st) {
+  hipLaunchKernelGGL(lk_append_sector_kernel, dim3(1), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t lk_launch_stale_iterations_blocks(lk_result *all, int n, int n_ranks, int cap, const int *carry_in, int *carry_out,
+                                             hipStream_t st) {
+  if (n <= 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(lk_stale_iterations_blocks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, all, n, n_ranks,
+                     cap, carry_in, carry_out);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------
 // launch wrappers (called from lk_engine.cpp)
 // ------------------------------------------------------------------------------------
@@ -3184,12 +3505,12 @@ template <class K> static int resident_workgroups(K kernel, int threads) {
   return cus * per_cu;
 }
 
-template <int MODEL, int INTERP, int GROUP, int THREADS, bool SAFE>
+template <int MODEL, int INTERP, int GROUP, int THREADS, bool SAFE, bool REF = false>
 static hipError_t launch_solve_gs(const LkSolveArgs &a, hipStream_t st) {
   static std::atomic<int> resident_cache{0}; // per template instance (one device type per process); engines launch from several threads
   int resident = resident_cache.load(std::memory_order_relaxed);
   if (resident == 0) {
-    resident = resident_workgroups(lk_solve_kernel<MODEL, INTERP, GROUP, THREADS, SAFE>, THREADS);
+    resident = resident_workgroups(lk_solve_kernel<MODEL, INTERP, GROUP, THREADS, SAFE, REF>, THREADS);
     resident_cache.store(resident, std::memory_order_relaxed);
   }
   const int per_wg = THREADS / GROUP;
@@ -3202,7 +3523,7 @@ static hipError_t launch_solve_gs(const LkSolveArgs &a, hipStream_t st) {
   b.persistent = force_persistent >= 0 ? force_persistent : (want > 2 * resident ? 1 : 0);
   if (GROUP == 1)
     b.persistent = 0; // every lane takes exactly one sector
-  if (GROUP == 16 && SAFE && a.resume && !a.finisher) {
+  if (GROUP == 16 && SAFE && !REF && a.resume && !a.finisher) {
     // sectors parked with a bad pivot: normally none - a small grid that retires at once and
     // rewinds its own list and queue (they start at zero: lk_commit_sectors)
     b.persistent = 1;
@@ -3212,7 +3533,7 @@ static hipError_t launch_solve_gs(const LkSolveArgs &a, hipStream_t st) {
                        st, b);
     return hipGetLastError();
   }
-  if (GROUP == 16 && SAFE && a.finisher) {
+  if (GROUP == 16 && SAFE && !REF && a.finisher) {
     // the finisher pulls parked sectors from finish_list until *finish_count (known only on
     // the device) is used up: as many wavefronts as could be needed, capped by what is resident
     b.persistent = 1;
@@ -3248,7 +3569,7 @@ static hipError_t launch_solve_gs(const LkSolveArgs &a, hipStream_t st) {
       return qe;
   }
   dim3 grid((unsigned)(b.persistent ? resident : 8 * b.chunk));
-  hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, GROUP, THREADS, SAFE>), grid, dim3(THREADS), 0, st, b);
+  hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, GROUP, THREADS, SAFE, REF>), grid, dim3(THREADS), 0, st, b);
   return hipGetLastError();
 }
 
@@ -3258,6 +3579,10 @@ static hipError_t launch_solve_gs(const LkSolveArgs &a, hipStream_t st) {
 // the GROUP == 1 kernel solves them first.
 template <int MODEL, int INTERP, int GROUP, int THREADS>
 static hipError_t launch_solve_g(const LkSolveArgs &a, hipStream_t st) {
+  if constexpr (THREADS == kWave && (GROUP == 16 || GROUP == kWave)) {
+    if (a.reference_order > 0) // the reference-order instances
+      return launch_solve_gs<MODEL, INTERP, GROUP, THREADS, true, true>(a, st);
+  }
   return a.safe ? launch_solve_gs<MODEL, INTERP, GROUP, THREADS, true>(a, st)
                 : launch_solve_gs<MODEL, INTERP, GROUP, THREADS, false>(a, st);
 }

@@ -40,6 +40,11 @@ class HipCorrelationGroup:
     def size(self):
         return self.lib.lk_group_size(self._h)
 
+    @property
+    def comm_ranks(self):
+        """ranks of the RCCL communicator as ncclCommCount reports them (0: the one-GPU rehearsal transport)"""
+        return self.lib.lk_group_comm_ranks(self._h)
+
     def engine_handle(self, rank):
         h = C.c_void_p()
         self._chk(self.lib.lk_group_engine(self._h, rank, C.byref(h)))

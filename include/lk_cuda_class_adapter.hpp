@@ -59,6 +59,7 @@ class HipCudaClass {
   int deviceCount_ = 1;
   bool sectors_dirty_ = false;
   CorrelationResult last_{};
+  int last_rc_ = LK_ERROR_NONE;
   std::vector<lk_result> batch_;
 
   static_assert(sizeof(CorrelationResult) == sizeof(lk_result), "lk_result must mirror CorrelationResult");
@@ -78,11 +79,16 @@ class HipCudaClass {
     engine_ = nullptr;
     group_ = nullptr;
   }
+  // Annular / blob sectors are rasterised at commit (on the device), so an empty one is reported HERE
+  // (LK_ERROR_BAD_DOMAIN) rather than by resetPolygon; a failed commit stays pending - the next call tries
+  // again after the caller re-registered the offending sector - and its code is what correlate() reports.
+  int commit_rc_ = LK_ERROR_NONE;
   bool commit() {
     if (!sectors_dirty_)
       return true;
-    sectors_dirty_ = false;
-    return (group_ ? lk_group_commit_sectors(group_) : lk_commit_sectors(engine_)) == LK_ERROR_NONE;
+    commit_rc_ = group_ ? lk_group_commit_sectors(group_) : lk_commit_sectors(engine_);
+    sectors_dirty_ = commit_rc_ != LK_ERROR_NONE;
+    return commit_rc_ == LK_ERROR_NONE;
   }
   // group mode: the engine that owns a global sector index and the sector's index there
   lk_engine *owner(int iSector, int *local) {
@@ -270,8 +276,9 @@ public:
   CorrelationResult *correlate(int iSector, float *initial_guess_, frame_results & /*results*/) {
     lk_result r{};
     int local = 0;
+    commit_rc_ = LK_ERROR_NONE;
     lk_engine *e = ensure_engine() && commit() ? owner(iSector, &local) : nullptr;
-    int rc = e ? lk_correlate(e, local, initial_guess_, &r) : LK_ERROR_DEVICE;
+    int rc = e ? lk_correlate(e, local, initial_guess_, &r) : (commit_rc_ ? commit_rc_ : LK_ERROR_DEVICE);
     if (rc)
       r.errorCode = rc;
     for (int i = 0; i < 6; ++i)
@@ -286,13 +293,20 @@ public:
   }
 
   // the batched fast path: every registered sector of the pair in one device-resident solve
+  // (nullptr on failure; lastError() tells why - e.g. error_bad_domain for an empty annular sector)
+  errorEnum lastError() const { return (errorEnum)last_rc_; }
   const CorrelationResult *correlateAll(const float *guesses /*[S][6]*/, int *count) {
-    if (!ensure_engine() || !commit())
+    last_rc_ = LK_ERROR_DEVICE;
+    commit_rc_ = LK_ERROR_NONE;
+    if (!ensure_engine() || !commit()) {
+      if (commit_rc_)
+        last_rc_ = commit_rc_;
       return nullptr;
+    }
     int S = group_ ? lk_group_sector_count(group_) : lk_sector_count(engine_);
     batch_.resize((size_t)S);
-    if ((group_ ? lk_group_correlate_all(group_, guesses, batch_.data()) : lk_correlate_all(engine_, guesses, batch_.data())) !=
-        LK_ERROR_NONE)
+    last_rc_ = group_ ? lk_group_correlate_all(group_, guesses, batch_.data()) : lk_correlate_all(engine_, guesses, batch_.data());
+    if (last_rc_ != LK_ERROR_NONE)
       return nullptr;
     if (count)
       *count = S;

@@ -199,7 +199,11 @@ int lk_set_sector_blob(lk_engine *e, int sector, const float *contour_xy, int n_
 int lk_set_sector_points(lk_engine *e, int sector, const float *xy, int n, int use_center,
                          float cx, float cy);
 /* build per-level sample lists (pyramid_class.cpp:289-362) and upload; must be called
- * after the lk_set_sector_* calls and before lk_correlate_*.  Sectors registered since the
+ * after the lk_set_sector_* calls and before lk_correlate_*.  Annular and blob sectors are
+ * registered by their description and rasterised HERE (on the device): a sector that turns
+ * out to be empty is reported by this call (LK_ERROR_BAD_DOMAIN, the message names the
+ * sector), not by lk_set_sector_annular / _blob - unless LK_HOST_ROI=1, where the host scan
+ * runs at registration like the reference's (manager_class.cpp:1028-1031).  Sectors registered since the
  * previous commit start with zeroed sequence state (guess history, last record); every other
  * sector keeps its state, so the reference's first-frame loop - resetPolygon(i), correlate(i),
  * sector after sector (manager_class.cpp:340, :449) - can commit once per sector and still
@@ -251,8 +255,13 @@ int lk_correlate(lk_engine *e, int sector, float *guess_inout, lk_result *out);
  * guesses: [S][6] host floats (unused slots ignored); out: [S] host records */
 int lk_correlate_all(lk_engine *e, const float *guesses, lk_result *out);
 /* same with device buffers, asynchronous on the engine's stream; d_guesses may be NULL
- * to use the engine-held guesses written by lk_adjust_initial_guess */
+ * to use the engine-held guesses written by lk_adjust_initial_guess; d_results may be NULL to
+ * leave the records in the engine's own record buffer (lk_get_results_device).  Note that
+ * lk_update_sector moves a sector by the engine's OWN record of it: a caller that solves into a
+ * buffer of its own and then calls lk_update_sector must copy the records back (lk_group does). */
 int lk_correlate_all_device(lk_engine *e, const void *d_guesses, void *d_results);
+/* the engine's own record buffer, [S] lk_result in device memory (valid until the next commit) */
+int lk_get_results_device(lk_engine *e, const void **d_records);
 /* lk_correlate_all with the engine-held guesses (lk_adjust_initial_guess) that does not wait: the
  * records follow the solve into an engine-owned pinned buffer; lk_wait_results blocks until they
  * are there and copies them to out [S].  One solve may be outstanding.  A frame loop uses the

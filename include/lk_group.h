@@ -26,7 +26,15 @@
  * Conventions as in lk_engine.h: every function returns an lk_error; the caller owns all buffers;
  * one caller thread at a time.  Records are bit-identical to what ONE engine gives for the same
  * sectors whenever the engine's records do not depend on batch composition
- * (lk_set_batch_invariant / lk_set_reference_order, applied to every member via lk_group_engine).
+ * (lk_set_batch_invariant / lk_set_reference_order, applied to every member via lk_group_engine) - in
+ * reference-order mode including the iteration count a sector reports when its very first evaluation fails
+ * (the count the sector BEFORE it left behind, correlation_class.cpp:413-419, :870: resolved over the gathered
+ * records in global sector order, with one carry for the whole group).
+ * The members' own record buffers hold their shards' records after a solve, so lk_update_sector on a member
+ * (HipCudaClass::updatePolygon) moves a sector by the right record.
+ * Failures: a member that fails before a collective makes the CALL fail on every member (nobody enters the
+ * collective); a collective that fails at enqueue aborts the communicators and breaks the group for good
+ * (every later call returns LK_ERROR_DEVICE) - it never hangs the caller.
  */
 #ifndef LK_GROUP_H
 #define LK_GROUP_H
@@ -43,11 +51,16 @@ typedef struct lk_group lk_group;
  * Distinct devices talk over RCCL (ncclCommInitAll).  Listing the same device more than once is
  * allowed for rehearsals on a one-GPU box: those ranks exchange frames and records with
  * device-to-device copies instead (RCCL refuses duplicate devices); everything else - threads,
- * sharding, padding, gather order - is the same code. */
+ * sharding, padding, gather order - is the same code.  (devices == NULL and the environment variable
+ * LK_GROUP_DEVICES=0,0,0 set: that list - the rehearsal hook for callers that only pass a count, like
+ * HipCudaClass::set_deviceCount.) */
 int lk_group_create(const lk_config *cfg, int n_devices, const int *devices, lk_group **out);
 void lk_group_destroy(lk_group *g);
 const char *lk_group_last_error_string(const lk_group *g);
 int lk_group_size(const lk_group *g);
+/* ranks of the group's RCCL communicator as RCCL itself reports them (ncclCommCount); 0 in the one-GPU rehearsal
+ * transport (the same device listed several times: copies and a host rendezvous, no communicator) */
+int lk_group_comm_ranks(const lk_group *g);
 /* member engine of a rank, for per-engine settings (lk_set_batch_invariant, lk_set_reference_order,
  * lk_get_stats ...); do not register sectors or images on it directly */
 int lk_group_engine(lk_group *g, int rank, lk_engine **e);

@@ -15,6 +15,7 @@ wl = getattr(workload, os.environ.get("LK_TRACE_CONFIG", "C2"))   # (C4 with -D'
 
 und, dfm = ca.speckle.speckle_pair(wl.size, wl.size, p=wl.truth, seed=7)
 e = ca.HipCorrelationEngine(fitting_model=wl.model, py_stop=wl.py_stop)
+e.set_reference_order(int(os.environ.get("LK_REF_ORDER", 0)))   # (with -D'LK_TRACE_PICK(G,S)=((S)&&(G)==16)': the reference-order instance)
 e.set_undeformed_image(und)
 e.set_deformed_image(dfm)
 grid = int(os.environ.get("LK_GRID", 0))   # another number of sectors of the same size (e.g. 32: wavefronts alone on their SIMDs)

@@ -8,6 +8,7 @@
 // (tests/host/lk_engine_mock.cpp, -DADAPTER_DRIVER_MOCK) in the build container, against
 // liblk_engine.so on the GPU box.
 //   adapter_driver und.raw def.raw nxt.raw rows cols x_begin x_end hs vs out.bin
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -54,6 +55,12 @@ int main(int argc, char **argv) {
 #ifndef ADAPTER_DRIVER_MOCK
   if (c.handle())
     lk_set_batch_invariant(c.handle(), 1); // a sector's record then does not depend on what else is in the launch
+  if (c.group_handle())
+    for (int r = 0; r < lk_group_size(c.group_handle()); ++r) {
+      lk_engine *e = nullptr;
+      if (lk_group_engine(c.group_handle(), r, &e) == LK_ERROR_NONE)
+        lk_set_batch_invariant(e, 1);
+    }
 #endif
   // sector geometry of the rectangular domain, manager_class.cpp:283-310
   const int x0 = (int)fx0, x1 = (int)fx1;
@@ -63,6 +70,7 @@ int main(int argc, char **argv) {
   std::vector<CorrelationResult> out((size_t)2 * S);
   std::vector<float> guess((size_t)6 * S, 0.f);
   frame_results fr{};
+  const auto t_f0 = std::chrono::steady_clock::now();
   for (int i = 0; i < hs; ++i)
     for (int j = 0; j < vs; ++j) {
       const int iSector = i * vs + j;
@@ -84,6 +92,7 @@ int main(int argc, char **argv) {
         guess[(size_t)6 * s + i] = all[s].resultingParameters[i];
     }
   }
+  const double ms_f0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_f0).count();
   // the preload queue (CudaClass::tempQ): the next frame comes from the queue, pushed ahead of time
   if (c.resetNextPyramid() == error_none) // nothing preloaded yet: must be refused
     return 10;
@@ -92,6 +101,7 @@ int main(int argc, char **argv) {
   if (c.resetNextPyramid() != error_none || c.preloaded.size() != 1)
     return 11;
   c.makeDefPyramidFromNxt();
+  const auto t_f1 = std::chrono::steady_clock::now();
   for (int iSector = 0; iSector < S; ++iSector) {
     c.updatePolygon(iSector, def_Lagrangian);
     if (devices == 1)
@@ -105,6 +115,8 @@ int main(int argc, char **argv) {
     for (int s = 0; s < S; ++s)
       out[(size_t)S + s] = all[s];
   }
+  const double ms_f1 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_f1).count();
+  std::printf("frame 0 (register + solve, sector by sector): %.1f ms; frame 1 (move + solve): %.1f ms\n", ms_f0, ms_f1);
   FILE *f = std::fopen(argv[10], "wb");
   if (!f || std::fwrite(out.data(), sizeof(CorrelationResult), out.size(), f) != out.size())
     return 7;

@@ -31,7 +31,7 @@ struct lk_engine {
   unsigned sum[3] = {0, 0, 0};
   bool valid[3] = {false, false, false};
   std::vector<float> guess, last_p, prev_p; // [S][6], engine-held (lk_adjust_initial_guess)
-  std::vector<lk_result> pending;
+  std::vector<lk_result> pending, own_records;
   bool outstanding = false;
   std::string err;
 };
@@ -203,6 +203,42 @@ int lk_correlate_all(lk_engine *e, const float *guesses, lk_result *out) {
   for (size_t s = 0; s < e->hs.size(); ++s)
     std::memcpy(&e->last_p[6 * s], out[s].resultingParameters, 6 * sizeof(float));
   J("correlate_all S=%zu", e->hs.size());
+  return 0;
+}
+// Device-buffer form, as the real engine has it ("device" memory is host memory here): records go to the
+// caller's buffer when one is given - and then NOT into the engine's own record buffer, which is what
+// lk_update_sector reads - or stay in the engine's own buffer (d_results = NULL, lk_get_results_device).
+int lk_correlate_all_device(lk_engine *e, const void *d_guesses, void *d_results) {
+  if (!e->committed || !e->valid[0] || !e->valid[1])
+    return LK_ERROR_BAD_DOMAIN;
+  const float *guesses = (const float *)d_guesses;
+  lk_result *ext = (lk_result *)d_results;
+  e->last_p.resize(6 * e->hs.size(), 0.f);
+  for (size_t s = 0; s < e->hs.size(); ++s) {
+    float g[6] = {0, 0, 0, 0, 0, 0};
+    if (guesses)
+      std::memcpy(g, guesses + 6 * s, sizeof g);
+    else if (e->guess.size() == 6 * e->hs.size())
+      std::memcpy(g, &e->guess[6 * s], sizeof g);
+    const lk_result r = fake_solve(e, e->hs[s], g);
+    if (ext) {
+      ext[s] = r;
+    } else {
+      e->hs[s].last = r;
+      e->hs[s].solved = true;
+    }
+    std::memcpy(&e->last_p[6 * s], r.resultingParameters, 6 * sizeof(float));
+  }
+  J("correlate_all_device S=%zu own=%d", e->hs.size(), ext ? 0 : 1);
+  return 0;
+}
+int lk_get_results_device(lk_engine *e, const void **d_records) {
+  if (!e->committed || !d_records)
+    return LK_ERROR_BAD_DOMAIN;
+  e->own_records.resize(e->hs.size());
+  for (size_t s = 0; s < e->hs.size(); ++s)
+    e->own_records[s] = e->hs[s].last;
+  *d_records = e->own_records.data();
   return 0;
 }
 // ---- what lk_sequence_frame / lk_sequence_run (lk_tracker.cpp) call besides the above ----------
@@ -416,8 +452,15 @@ int lk_group_correlate_all(lk_group *g, const float *guesses, lk_result *out) {
   for (int r = 0; r < n; ++r) {
     int first, count;
     lk_group_shard_range(S, r, n, &first, &count);
-    if (int rc = lk_correlate_all(g->e[(size_t)r], guesses ? guesses + 6 * (size_t)first : nullptr, out + first))
+    // the real group's data flow (csrc/lk_group.cpp): the member solves into ITS OWN record buffer - the one
+    // lk_update_sector reads - and the block for the gather is copied from there
+    if (int rc = lk_correlate_all_device(g->e[(size_t)r], guesses ? guesses + 6 * (size_t)first : nullptr, nullptr))
       return rc;
+    const void *own = nullptr;
+    if (int rc = lk_get_results_device(g->e[(size_t)r], &own))
+      return rc;
+    if (out)
+      std::memcpy(out + first, own, (size_t)count * sizeof(lk_result));
   }
   J("group_correlate_all S=%d", S);
   return 0;

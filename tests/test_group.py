@@ -127,6 +127,41 @@ def test_group_of_several_ranks_equals_the_engine(oracle, speckle512, n_ranks):
 
 
 @pytest.mark.gpu
+def test_group_in_reference_order_mode_carries_the_stale_iteration_count_across_shards(oracle, speckle512):
+    """Reference-order mode: a sector whose very first evaluation fails reports the iteration count the sector
+    BEFORE it left behind (correlation_class.cpp:413-419, :870).  In a group the sector before the first one of
+    a shard lives on another rank: the markers are resolved over the gathered records, in global order."""
+    und, dfm = speckle512
+    bad = oracle.rect_points(0, 0, 20, 20)           # out of the image at evaluation #0 of the coarsest level
+    good = [oracle.rect_points(60 + 40 * i, 80 + 30 * i, 90 + 40 * i, 105 + 30 * i) for i in range(9)]
+    lists, cens = [], []
+    for s in range(9):                                # shards of 3 ranks: [0,3) [3,6) [6,9); failing sectors lead shards 1 and 2
+        if s in (3, 4, 6):
+            lists.append(bad), cens.append((10.0, 10.0))
+        else:
+            lists.append(good[s]), cens.append((75.0 + 40 * s, 92.0 + 30 * s))
+    o = oracle.Oracle()
+    o.set_image(0, und)
+    o.set_image(1, dfm)
+    want = o.correlate_sectors(lists, centers=np.array(cens, np.float32))
+    assert list(want["error_code"][[3, 4, 6]]) == [2, 2, 2] and want["iterations"][3] == want["iterations"][2] > 0
+    for n_ranks in (1, 3):
+        g = ca.HipCorrelationGroup([0] * n_ranks)
+        g.for_each_engine("lk_set_reference_order", 1)
+        g.set_image(ca.IMG_UND, und)
+        g.set_image(ca.IMG_DEF, dfm)
+        for s in range(9):
+            g.set_sector_points(s, lists[s], center=cens[s])
+        g.commit_sectors()
+        got = g.correlate_all(np.zeros(6, np.float32))
+        assert got.tobytes() == want.tobytes(), (n_ranks, got["iterations"], want["iterations"])
+        # the carry into the NEXT solve is the last sector's count: solve again with the failing sector first
+        got2 = g.correlate_all(np.zeros(6, np.float32))
+        assert got2.tobytes() == want.tobytes()
+        g.close()
+
+
+@pytest.mark.gpu
 def test_group_tracks_a_constant_velocity_sequence():
     """BASELINE config 4's shape: the guess history lives with the engine that owns the sector; per frame
     only the new image goes out and the records come back (und fixed, def <- nxt rotation)."""
