@@ -895,33 +895,48 @@ __device__ __forceinline__ bool evaluate_ordered_flat(const LevelCtx &c, const f
   const int cq = c.n / T, cr = c.n - cq * T; // thread chunks of the reference: chunk t has n/T + (t < n%T) samples
   int t_idx = 0, next_b = cq + (cr > 0 ? 1 : 0), kpos = 0;
   unsigned bad_sectors = 0u; // bit r: a sample of sector r left the image
-  // the context of the sector my tile row works for (reloaded only when the deal changes)
-  OrdCtx e{};
+  OrdCtx e{};                // the context of the sector my tile row works for (reloaded only when the deal changes)
   int cur = -1;
+  // A DEAL says which sector each tile row works for: every busy sector gets one row, the rows left over go,
+  // one by one, to the busy sector with the most slots left per row; then the sectors take their rows as consecutive
+  // runs of tile rows, in sector order (nobody needs its "own" row: every lane fetches its sector's context from
+  // LDS).  A sector's rows in ascending order are consecutive slots, i.e. its samples in order.  A deal lasts for
+  // as many trips as every busy sector can fill all its rows (the inner loop: no scalar work besides the trip
+  // count); then the next deal - a handful per evaluation.  All of this is wavefront-uniform scalar work.
   while ((rem[0] | rem[1] | rem[2] | rem[3]) != 0) {
-    // deal the four tile rows: most slots left first (ties: the lower sector)
-    int sec[4], k0[4];
-    unsigned rows_of[4] = {0u, 0u, 0u, 0u};
+    int cnt[4], spare = 4;
 #pragma unroll
-    for (int tr = 0; tr < 4; ++tr) {
-      int best = 0, bv = rem[0];
+    for (int r = 0; r < 4; ++r) {
+      cnt[r] = rem[r] > 0 ? 1 : 0;
+      spare -= cnt[r];
+    }
+    for (; spare > 0; --spare) {
+      int best = -1, best_rem = 0, best_cnt = 1;
 #pragma unroll
-      for (int r = 1; r < 4; ++r)
-        if (rem[r] > bv)
-          bv = rem[r], best = r;
-      sec[tr] = bv > 0 ? best : -1;
-      k0[tr] = 0;
+      for (int r = 0; r < 4; ++r) // (a sector that is not busy has rem = cnt = 0 and never qualifies)
+        if (rem[r] > cnt[r] && (best < 0 || rem[r] * best_cnt > best_rem * cnt[r]))
+          best = r, best_rem = rem[r], best_cnt = cnt[r];
+      if (best < 0)
+        break;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (bv > 0 && best == r) {
-          k0[tr] = used[r] << 4;
-          ++used[r];
-          --rem[r];
-          rows_of[r] |= 1u << tr;
-        }
+        cnt[r] += best == r ? 1 : 0;
     }
-    const int my_sec = row == 0 ? sec[0] : row == 1 ? sec[1] : row == 2 ? sec[2] : sec[3];
-    const int my_k0 = row == 0 ? k0[0] : row == 1 ? k0[1] : row == 2 ? k0[2] : k0[3];
+    const int off1 = cnt[0], off2 = off1 + cnt[1], off3 = off2 + cnt[2], off4 = off3 + cnt[3]; // first tile row of sectors 1, 2, 3; rows in use
+    int trips = 0x7fffffff; // every busy sector fills all its rows in each of them
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (cnt[r] > 0)
+        trips = min(trips, rem[r] / cnt[r]);
+    // my tile row: its sector and its rank among the sector's rows; my home row: my own sector's run of tile rows
+    const int my_sec = row >= off4 ? -1 : (row >= off1 ? 1 : 0) + (row >= off2 ? 1 : 0) + (row >= off3 ? 1 : 0);
+    const int sec_off = my_sec == 1 ? off1 : my_sec == 2 ? off2 : my_sec == 3 ? off3 : 0;
+    const int my_rank = row - sec_off;
+    const int sec_used = my_sec == 0 ? used[0] : my_sec == 1 ? used[1] : my_sec == 2 ? used[2] : used[3];
+    const int sec_cnt = my_sec == 0 ? cnt[0] : my_sec == 1 ? cnt[1] : my_sec == 2 ? cnt[2] : cnt[3];
+    const int my_first = row == 0 ? 0 : row == 1 ? off1 : row == 2 ? off2 : off3;
+    const int my_cnt = row == 0 ? cnt[0] : row == 1 ? cnt[1] : row == 2 ? cnt[2] : cnt[3];
+    const int most = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3]));
     if (__any(my_sec >= 0 && my_sec != cur)) {
       const int want = my_sec >= 0 ? my_sec : (cur >= 0 ? cur : 0);
       const float4 *src = reinterpret_cast<const float4 *>(ctx + want);
@@ -931,106 +946,114 @@ __device__ __forceinline__ bool evaluate_ordered_flat(const LevelCtx &c, const f
         dst[i] = src[i];
       cur = want;
     }
-    const int k = my_k0 + g;
-    float t[N];
+    gptr<uint8_t> und = (gptr<uint8_t>)(uintptr_t)(((unsigned long long)e.und_hi << 32) | e.und_lo);
+    gptr<uint8_t> def = (gptr<uint8_t>)(uintptr_t)(((unsigned long long)e.def_hi << 32) | e.def_lo);
+    gptr<f32x2> xyl = (gptr<f32x2>)(uintptr_t)(((unsigned long long)e.xy_hi << 32) | e.xy_lo);
+    const int n_mine = my_sec >= 0 ? e.n : 0; // (a row without a sector forms no products)
+    int k = ((sec_used + my_rank) << 4) + g;  // my sample in the first trip of this deal; + 16 * sec_cnt per trip
+    const int k_step = sec_cnt << 4;
+    for (int trip = 0; trip < trips; ++trip, k += k_step) {
+      float t[N];
 #pragma unroll
-    for (int v = 0; v < N; ++v)
-      t[v] = 0.f;
-    bool bad = false;
-    if (my_sec >= 0 && k < e.n) {
-      f32x2 q;
-      if (e.rw > 0) { // x outer, y inner: k -> (column, row) of the rectangle
-        const int rh = e.rh;
-        int col = (int)((float)k * e.inv_rh); // k / rh to within one unit below 2^23 samples, two below 2^25
-        int rr = k - col * rh;
+      for (int v = 0; v < N; ++v)
+        t[v] = 0.f;
+      bool bad = false;
+      if (k < n_mine) {
+        f32x2 q;
+        if (e.rw > 0) { // x outer, y inner: k -> (column, row) of the rectangle
+          const int rh = e.rh;
+          int col = (int)((float)k * e.inv_rh); // k / rh to within one unit below 2^23 samples, two below 2^25
+          int rr = k - col * rh;
 #pragma unroll
-        for (int fix = 0; fix < 2; ++fix) {
-          const int lo = rr < 0 ? 1 : 0, hi = rr >= rh ? 1 : 0;
-          rr += (lo - hi) * rh;
-          col += hi - lo;
-        }
-        q.x = (float)(e.rx + col);
-        q.y = (float)(e.ry + rr);
-      } else {
-        q = ((gptr<f32x2>)(uintptr_t)(((unsigned long long)e.xy_hi << 32) | e.xy_lo))[k];
-      }
-      gptr<uint8_t> und = (gptr<uint8_t>)(uintptr_t)(((unsigned long long)e.und_hi << 32) | e.und_lo);
-      gptr<uint8_t> def = (gptr<uint8_t>)(uintptr_t)(((unsigned long long)e.def_hi << 32) | e.def_lo);
-      float xd, yd, dx = 0.f, dy = 0.f;
-      Warp<MODEL>::apply(q.x, q.y, e.cx, e.cy, e.p, xd, yd, dx, dy);
-      int uix = (int)(q.x + 0.5f), uiy = (int)(q.y + 0.5f);
-      uix = min(max(uix, 0), e.ucols - 1);
-      uiy = min(max(uiy, 0), e.urows - 1);
-      const float und_w = (float)und[(size_t)uiy * (size_t)e.ucols + (size_t)uix];
-      float W, Wx, Wy;
-      if (!sample_def<INTERP>(def, e.drows, e.dcols, xd, yd, W, Wx, Wy)) {
-        bad = true; // (the sums of an evaluation that hit the error are never used)
-      } else {
-        const float V = und_w - W;
-        float H[P];
-        Warp<MODEL>::jac(Wx, Wy, dx, dy, H);
-        int idx = 0;
-#pragma unroll
-        for (int p1 = 0; p1 < P; ++p1)
-#pragma unroll
-          for (int p2 = p1; p2 < P; ++p2)
-            t[idx++] = H[p1] * H[p2]; // rounded product; the rounded add follows below
-#pragma unroll
-        for (int p1 = 0; p1 < P; ++p1)
-          t[SumsT::NA + p1] = H[p1] * V;
-        t[N - 1] = V * V;
-      }
-    }
-    {
-      const unsigned long long bm = __ballot(bad);
-#pragma unroll
-      for (int tr = 0; tr < 4; ++tr)
-        if (sec[tr] >= 0 && ((bm >> (16 * tr)) & 0xffffull) != 0ull)
-          bad_sectors |= 1u << sec[tr];
-    }
-    // transpose: my product of sum v -> tile[v][lane]
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the previous trip's reads are done
-#pragma unroll
-    for (int v = 0; v < N; ++v)
-      tile[v * STR + lane] = t[v];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // the home rows add what their sectors got in this trip, tile rows in ascending order = sample order
-    unsigned mine = row == 0 ? rows_of[0] : row == 1 ? rows_of[1] : row == 2 ? rows_of[2] : rows_of[3];
-    const int most = max(max(__builtin_popcount(rows_of[0]), __builtin_popcount(rows_of[1])),
-                         max(__builtin_popcount(rows_of[2]), __builtin_popcount(rows_of[3])));
-    for (int j = 0; j < most; ++j) {
-      if (mine != 0u) {
-        const int tr = __builtin_ctz(mine);
-        mine &= mine - 1u;
-        const float *r0 = tile + v0 * STR + 16 * tr, *r1 = tile + v1 * STR + 16 * tr;
-#pragma unroll
-        for (int j4 = 0; j4 < 4; ++j4) {
-          const float4 a4 = *reinterpret_cast<const float4 *>(r0 + 4 * j4);
-          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          if constexpr (TWO)
-            b4 = *reinterpret_cast<const float4 *>(r1 + 4 * j4);
-          const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            if (CHUNKED && kpos + 4 * j4 + jj == next_b) { // a thread chunk ends before this sample (:253-275)
-              tot0 += acc0;
-              acc0 = 0.f;
-              if constexpr (TWO) {
-                tot1 += acc1;
-                acc1 = 0.f;
-              }
-              ++t_idx;
-              next_b += cq + (t_idx < cr ? 1 : 0);
-            }
-            acc0 += av[jj];
-            if constexpr (TWO)
-              acc1 += bv[jj];
+          for (int fix = 0; fix < 2; ++fix) {
+            const int lo = rr < 0 ? 1 : 0, hi = rr >= rh ? 1 : 0;
+            rr += (lo - hi) * rh;
+            col += hi - lo;
           }
+          q.x = (float)(e.rx + col);
+          q.y = (float)(e.ry + rr);
+        } else {
+          q = xyl[k];
         }
-        kpos += 16;
+        float xd, yd, dx = 0.f, dy = 0.f;
+        Warp<MODEL>::apply(q.x, q.y, e.cx, e.cy, e.p, xd, yd, dx, dy);
+        int uix = (int)(q.x + 0.5f), uiy = (int)(q.y + 0.5f);
+        uix = min(max(uix, 0), e.ucols - 1);
+        uiy = min(max(uiy, 0), e.urows - 1);
+        const float und_w = (float)und[(size_t)uiy * (size_t)e.ucols + (size_t)uix];
+        float W, Wx, Wy;
+        if (!sample_def<INTERP>(def, e.drows, e.dcols, xd, yd, W, Wx, Wy)) {
+          bad = true; // (the sums of an evaluation that hit the error are never used)
+        } else {
+          const float V = und_w - W;
+          float H[P];
+          Warp<MODEL>::jac(Wx, Wy, dx, dy, H);
+          int idx = 0;
+#pragma unroll
+          for (int p1 = 0; p1 < P; ++p1)
+#pragma unroll
+            for (int p2 = p1; p2 < P; ++p2)
+              t[idx++] = H[p1] * H[p2]; // rounded product; the rounded add follows below
+#pragma unroll
+          for (int p1 = 0; p1 < P; ++p1)
+            t[SumsT::NA + p1] = H[p1] * V;
+          t[N - 1] = V * V;
+        }
       }
+      {
+        const unsigned long long bm = __ballot(bad);
+        if (bm != 0ull) {
+#pragma unroll
+          for (int tr = 0; tr < 4; ++tr)
+            if (tr < off4 && ((bm >> (16 * tr)) & 0xffffull) != 0ull)
+              bad_sectors |= 1u << ((tr >= off1 ? 1 : 0) + (tr >= off2 ? 1 : 0) + (tr >= off3 ? 1 : 0));
+        }
+      }
+      // transpose: my product of sum v -> tile[v][lane]
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the previous trip's reads are done
+#pragma unroll
+      for (int v = 0; v < N; ++v)
+        tile[v * STR + lane] = t[v];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // the home rows add what their sectors got in this trip, tile rows in ascending order = sample order
+      for (int j = 0; j < most; ++j) {
+        if (j < my_cnt) {
+          const int tr = my_first + j;
+          const float *r0 = tile + v0 * STR + 16 * tr, *r1 = tile + v1 * STR + 16 * tr;
+#pragma unroll
+          for (int j4 = 0; j4 < 4; ++j4) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(r0 + 4 * j4);
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (TWO)
+              b4 = *reinterpret_cast<const float4 *>(r1 + 4 * j4);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              if (CHUNKED && kpos + 4 * j4 + jj == next_b) { // a thread chunk ends before this sample (:253-275)
+                tot0 += acc0;
+                acc0 = 0.f;
+                if constexpr (TWO) {
+                  tot1 += acc1;
+                  acc1 = 0.f;
+                }
+                ++t_idx;
+                next_b += cq + (t_idx < cr ? 1 : 0);
+              }
+              acc0 += av[jj];
+              if constexpr (TWO)
+                acc1 += bv[jj];
+            }
+          }
+          kpos += 16;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      used[r] += trips * cnt[r];
+      rem[r] -= trips * cnt[r];
     }
   }
   tot0 += acc0; // the last chunk (T == 1: 0 + acc)
