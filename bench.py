@@ -436,6 +436,8 @@ def main():
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            os.environ.pop("NCCL_DEBUG")   # (RCCL's version banner goes to stdout, where the ONE JSON line is expected)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL
 
     wl = {"C2": C2, "C4": C4, "C4B": C4B, "C5": C5}[args.workload]

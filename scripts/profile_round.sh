@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the evidence kept under profiles/ on the GPU box (run through gpurun from the repo root):
-#   scripts/profile_round.sh r02
+#   scripts/profile_round.sh r03
 # 1. bench.py (default command: one pair at a time) under rocprofv3 --kernel-trace --stats
 #    -> <tag>_bench.json, <tag>_bench_kernel_stats.csv
 # 2. separate --pmc passes on scripts/quick_solve.py (HBM traffic, L2, SQ activity) -> <tag>_pmc_summary.txt,
@@ -10,7 +10,7 @@
 #    one C2 launch -> <tag>_wave_timeline.txt
 # PMC passes never share a run with tracing (pool rule) and the program follows `--` directly.
 set -uo pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
@@ -26,23 +26,56 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_s
   echo "pass $i done" >> "$out/progress.log"
 done
 python3 scripts/summarize_pmc.py "$out" "$tag" > "$out/${tag}_pmc_summary.txt"
-python3 - "$out/${tag}_pmc_summary.txt" "$tag" > "$out/${tag}_traffic.json" <<'PY'
+rm -rf "$out"/pmc*/
+# the same passes in reference-order mode (lk_set_reference_order(1): the 16-lane reference-order instance)
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  i=$((i + 1))
+  LK_REF_ORDER=1 timeout -k 10 120 rocprofv3 --pmc $set --output-format csv -d "$out/pmc$i" -o pmc -- python3 scripts/quick_solve.py C2 5 > "$out/rpmc$i.log" 2>&1 || echo "reference-order pass $i ($set) failed" >> "$out/progress.log"
+  echo "reference-order pass $i done" >> "$out/progress.log"
+done
+python3 scripts/summarize_pmc.py "$out" "$tag (LK_REF_ORDER=1)" > "$out/${tag}_reforder_pmc.txt"
+python3 - "$out/${tag}_pmc_summary.txt" "$out/${tag}_reforder_pmc.txt" "$tag" > "$out/${tag}_traffic.json" <<'PY'
 import json, re, sys
-kib = {}
-for line in open(sys.argv[1]):
-    m = re.match(r"lk_solve_kernel<3,\s*2,\s*32,\s*64,\s*false>\s+(FETCH_SIZE|WRITE_SIZE)\s+dispatches=\d+ mean=([0-9.e+]+)", line)
-    if m:
-        kib[m.group(1)] = float(m.group(2))
-print(json.dumps({"solve_kernel_hbm_bytes_per_launch_C2": (kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024.0,
-                  "source": f"profiles/{sys.argv[2]}_pmc_summary.txt (FETCH_SIZE + WRITE_SIZE of lk_solve_kernel<3,2,32,64,false>, KiB per dispatch; "
-                            "these byte / dword loads read 1:1 on the counter, calibrated on the pyramid kernel in profiles/r01_pmc_traffic.txt)"}, indent=1))
+
+
+def means(path, kernel):
+    out = {}
+    for line in open(path):
+        m = re.match(re.escape(kernel) + r"\s+(\w+)\s+dispatches=\d+ mean=([0-9.e+]+)", line)
+        if m:
+            out[m.group(1)] = float(m.group(2))
+    return out
+
+
+d = means(sys.argv[1], "lk_solve_kernel<3, 2, 32, 64, false, false>")
+r = means(sys.argv[2], "lk_solve_kernel<3, 2, 16, 64, true, true>")
+tag = sys.argv[3]
+print(json.dumps({
+    "solve_kernel_hbm_bytes_per_launch_C2": (d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0,
+    "solve_kernel_valu_insts_per_launch_C2": d["SQ_INSTS_VALU"],
+    "reference_order_hbm_bytes_per_launch_C2": (r["FETCH_SIZE"] + r["WRITE_SIZE"]) * 1024.0,
+    "reference_order_valu_insts_per_launch_C2": r["SQ_INSTS_VALU"],
+    "source": f"profiles/{tag}_pmc_summary.txt (lk_solve_kernel<3,2,32,64,false,false>) and profiles/{tag}_reforder_pmc.txt "
+              "(lk_solve_kernel<3,2,16,64,true,true>): FETCH_SIZE + WRITE_SIZE in KiB per dispatch (these byte / dword loads read 1:1 on "
+              "the counter, calibrated on the pyramid kernel in profiles/r01_pmc_traffic.txt), SQ_INSTS_VALU summed over the device"}, indent=1))
 PY
 timeout -k 10 200 rocprofv3 --kernel-trace -d "$out/c4" -o t -- python3 scripts/quick_solve.py C4 10 > "$out/c4.log" 2>&1
 { grep solve_ms "$out/c4.log"; python3 scripts/c4_chain_timeline.py "$out/c4/t_results.db" 8; } > "$out/${tag}_c4_chain.txt" 2>&1
 if [ -f build/tune/liblk_trace.so ]; then
-  LK_ENGINE_LIB=build/tune/liblk_trace.so timeout -k 10 120 python3 scripts/trace_solve.py "$out/trace_c2.npz" > /dev/null 2>&1 &&
+  LK_ENGINE_LIB=$PWD/build/tune/liblk_trace.so timeout -k 10 120 python3 scripts/trace_solve.py "$out/trace_c2.npz" > /dev/null 2>&1 &&
     { python3 scripts/trace_brief.py "$out/trace_c2.npz"; python3 scripts/trace_report.py "$out/trace_c2.npz"; } > "$out/${tag}_wave_timeline.txt" 2>&1
 fi
-rm -rf "$out/c4" "$out"/pmc*/ "$out/trace"
+if [ -f build/tune/liblk_trace_ord.so ]; then   # scripts/tune_build.sh trace_ord -DLK_TRACE '-DLK_TRACE_PICK(G,S)=((S)&&(G)==16)'
+  LK_REF_ORDER=1 LK_ENGINE_LIB=$PWD/build/tune/liblk_trace_ord.so timeout -k 10 120 python3 scripts/trace_solve.py "$out/trace_c2_ord.npz" > /dev/null 2>&1 &&
+    { python3 scripts/trace_brief.py "$out/trace_c2_ord.npz"; python3 scripts/trace_report.py "$out/trace_c2_ord.npz"; python3 scripts/trace_top.py "$out/trace_c2_ord.npz" 8; } > "$out/${tag}_reforder_wave_timeline.txt" 2>&1
+fi
+if [ -f build/tune/liblk_trace_ord_fine.so ]; then   # ... -DLK_TRACE_FINE: cycles per step split into fetch / evaluation / solve / rest
+  LK_REF_ORDER=1 LK_ENGINE_LIB=$PWD/build/tune/liblk_trace_ord_fine.so timeout -k 10 120 python3 scripts/trace_solve.py "$out/trace_c2_ord_fine.npz" > /dev/null 2>&1 &&
+    { python3 scripts/trace_fine.py "$out/trace_c2_ord_fine.npz"; python3 scripts/trace_top.py "$out/trace_c2_ord_fine.npz" 8; } >> "$out/${tag}_reforder_wave_timeline.txt" 2>&1
+fi
+# the one-rank rehearsal of the multi-process bench (RCCL in the loop, every block of the N > 1 line)
+LK_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout -k 10 400 python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-other-configs > "$out/${tag}_bench_dist_rehearsal.json" 2> "$out/bench_dist.err"
+rm -rf "$out/c4" "$out"/pmc*/ "$out/trace" "$out"/*.npz
 tail -1 "$out/${tag}_bench.json" | cut -c1-400
 cat "$out/${tag}_pmc_summary.txt"
