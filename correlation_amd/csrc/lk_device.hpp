@@ -27,13 +27,9 @@ struct LkHandoff {
   int level_old;     // level the parameters are scaled for
   int reached;       // reached_iterations so far (correlation_class.cpp:452)
   uint32_t n_evals, n_sample_evals, n_point_iters;
-  int early;         // 1: handed over by the starved-level kernel itself (not via the finisher) - a sector of the "ready list",
-                     //    which a lane-group launch may solve while the starved-level launches still run; 2: and taken by it
 };
 
 constexpr int kLkMidWords = 32; // Cold (23) + p (6) + phase
-constexpr uint32_t kLkReadyEmpty = 0xffffffffu, kLkReadyTaken = 0x80000000u;
-constexpr int kLkReadyCtrWords = 96;
 
 struct LkSolveArgs {
   const LkLevelView *lv; // [LK_MAX_LEVELS] in device memory
@@ -65,20 +61,6 @@ struct LkSolveArgs {
   uint32_t *finish_list;  // [S]
   uint32_t *finish_count; // [1], zeroed before the starved-level kernel
   LkHandoff *handoff;    // [S] written by the starved-level kernel, read by the others (may be null)
-  // The ready list: sectors whose starved levels the one-lane kernel finished by itself are published as they
-  // are handed over, so that a lane-group launch on a sibling stream can solve their remaining levels WHILE the
-  // starved-level launches (one-lane kernel, finisher) are still running - those leave most of the chip idle.
-  //   ready_mode 1  producer (the one-lane kernel): publishes
-  //              2  concurrent consumer (16-lane fast instance): takes entries as they appear, marks the sector's
-  //                 hand-over record (early = 2), leaves when the stop word is set (a one-thread kernel behind the
-  //                 starved-level launches; bounded wait besides)
-  //              4  the regular pass over the class, afterwards: skips the sectors the consumer took
-  // Every sector of such a class is solved with the fixed 16-lane grouping, whoever solves it - records do not
-  // depend on who got there first.
-  uint32_t *ready_list;  // [S]: kLkReadyEmpty (reset before every solve), a sector index, or a taken index (| kLkReadyTaken)
-  uint32_t *ready_ctr;   // [kLkReadyCtrWords]: published / the consumer's tickets / stop word, each on a 128-byte line of its
-                         //   own (lk_kernels.hip, RC_*)
-  int ready_mode;
   uint32_t *queue;       // next unclaimed slot of this launch (persistent mode), zeroed per launch
   int n_sectors;         // sectors in this launch
   int chunk;             // non-persistent: ceil(#workgroups / 8), XCD-contiguous chunk length

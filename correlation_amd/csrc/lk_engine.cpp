@@ -52,7 +52,6 @@ hipError_t lk_launch_roi_fill(const LkRoiSector *sectors, const LkRoiFlat *flats
                               uint32_t n_tiles, const uint32_t *tiles, float2 *xy, uint32_t *off, hipStream_t st);
 hipError_t lk_launch_stale_iterations(lk_result *r, int n, const int *carry_in, int *carry_out, hipStream_t st);
 hipError_t lk_launch_append_sector(const LkAppendArgs &a, hipStream_t st);
-hipError_t lk_launch_ready_stop(uint32_t *ready_ctr, hipStream_t st);
 hipError_t lk_launch_mean_center(const float2 *xy, const uint32_t *off, int n_sectors, float2 *center, hipStream_t st);
 size_t lk_mean_center_int_scratch_bytes(uint32_t n_samples, int n_sectors);
 hipError_t lk_launch_mean_center_int(const float2 *xy, const uint32_t *off, uint32_t n_samples, int n_sectors, void *scratch,
@@ -258,12 +257,6 @@ struct lk_engine {
   DevBuf<LkHandoff> d_handoff;
   DevBuf<uint32_t> d_mid, d_finish_list, d_finish_count; // stragglers of the starved-level kernel
   DevBuf<uint32_t> d_ill_list, d_ill_count;              // sectors whose damped system met a bad pivot
-  // the ready list (LkSolveArgs::ready_list): early sectors of a class with starved levels, solved by a lane-group
-  // launch on a sibling stream while the starved-level launches are still running
-  DevBuf<uint32_t> d_ready_list, d_ready_ctr;
-  hipStream_t ready_stream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_ready_fork[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
-             ev_ready_join[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   DevBuf<uint32_t> d_mean_scratch;                       // chunk table / sums / maps of lk_mean_center_int_kernel
   int starved_max = -1; // LK_STARVED_MAX as read by the last commit (-1: the default, 2 P)
   int eval_cap = 20; // evaluations a lane of the starved-level kernel spends on one sector (0: no cap; config 4: 12 / 16 / 20 / 24 / 32 -> 2.00 / 1.91 / 1.88 / 1.92 / 2.08 ms)
@@ -1329,9 +1322,6 @@ static int commit_impl(lk_engine *e, bool keep_state) {
   HIPCHK(e->d_ill_list.ensure((size_t)S));
   HIPCHK(e->d_ill_count.ensure(kNumClasses)); // one list region and one counter per class: classes solve concurrently
   HIPCHK(hipMemset(e->d_ill_count.p, 0, kNumClasses * sizeof(uint32_t)));
-  HIPCHK(e->d_ready_list.ensure((size_t)S));
-  HIPCHK(hipMemset(e->d_ready_list.p, 0xff, (size_t)S * sizeof(uint32_t))); // kLkReadyEmpty; every solve leaves it that way
-  HIPCHK(e->d_ready_ctr.ensure((size_t)kLkReadyCtrWords * kNumClasses));
   if (const char *f = std::getenv("LK_EVAL_CAP")) // tuning / test hook
     e->eval_cap = std::atoi(f);
   HIPCHK(e->d_scratch.ensure(64));
@@ -1394,10 +1384,6 @@ static int append_rect_sectors(lk_engine *e) {
     HIPCHK(e->d_ill_list.ensure(2 * want + 64));
   if (e->d_order.n < want)
     HIPCHK(e->d_order.ensure(2 * want + 64));
-  if (e->d_ready_list.n < want) {
-    HIPCHK(e->d_ready_list.ensure(2 * want + 64));
-    HIPCHK(hipMemset(e->d_ready_list.p, 0xff, e->d_ready_list.n * sizeof(uint32_t)));
-  }
   e->h_center.resize(2 * want);
   e->h_class.resize(want, 0);
   bool any_starved = false;
@@ -2025,7 +2011,6 @@ static int launch_starved(lk_engine *e, LkSolveArgs &a, int c, int first, hipStr
   if (a.eval_cap > 0) {
     LkSolveArgs f = a;
     f.finisher = 1;
-    f.ready_mode = 0;
     f.safe = 1;
     f.align = 0; // one trip per evaluation whatever the level: rows take the next parked sector as they finish
     HIPCHK(lk_launch_solve(f, e->cfg.fitting_model, e->cfg.interpolation, 16, st));
@@ -2159,57 +2144,14 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
       }
     }
     if (e->class_starved[c]) { // coarsest level(s) first, one lane per sector (+ finisher)
-      // Ready list (LkSolveArgs::ready_list; OFF by default, LK_OVERLAP=1 switches it on).  The starved-level launches
-      // leave much of the chip idle (config 4: 784 wavefronts for 0.37 ms, then a finisher that waits on QR chains)
-      // while four fifths of the sectors are through their starved levels early: those are published as they are handed
-      // over, and a lane-group launch on a sibling stream solves their remaining levels at once, until a one-thread
-      // kernel behind the starved-level launches tells it to stop; the regular pass takes the rest.  Records are
-      // byte-identical to the batch-invariant run (scripts/overlap_check.py, tests) - but every sector of the class must
-      // then use ONE arithmetic whoever solves it, i.e. the fixed 16-lane grouping without adaptive width, and that
-      // costs what the overlap gains (MI355X, round 3: config 4 1.90 ms off / 1.93 on / 2.06 batch-invariant off;
-      // config 5 5.6 / 8.1; 9x9-sample sectors 1.67 / 2.4 - the consumer also takes slots and L2 from the launches it
-      // runs beside).  Kept as an experiment, not as the default.
-      static const bool ready_env = [] { const char *f = std::getenv("LK_OVERLAP"); return f ? std::atoi(f) != 0 : false; }();
-      const bool use_ready = ready_env && kGroupOfClass[c] == 16 && !a.safe && e->eval_cap > 0;
-      LkSolveArgs consumer{};
-      if (use_ready) {
-        a.ready_list = e->d_ready_list.p + e->class_begin[c];
-        a.ready_ctr = e->d_ready_ctr.p + kLkReadyCtrWords * c;
-        HIPCHK(hipMemsetAsync(a.ready_ctr, 0, kLkReadyCtrWords * sizeof(uint32_t), st));
-        HIPCHK(hipMemsetAsync(a.ready_list, 0xff, (size_t)n * sizeof(uint32_t), st)); // kLkReadyEmpty
-        if (!e->ready_stream[c]) {
-          HIPCHK(hipStreamCreateWithFlags(&e->ready_stream[c], hipStreamNonBlocking));
-          HIPCHK(hipEventCreateWithFlags(&e->ev_ready_fork[c], hipEventDisableTiming));
-          HIPCHK(hipEventCreateWithFlags(&e->ev_ready_join[c], hipEventDisableTiming));
-        }
-        HIPCHK(hipEventRecord(e->ev_ready_fork[c], st));
-        HIPCHK(hipStreamWaitEvent(e->ready_stream[c], e->ev_ready_fork[c], 0));
-        a.ready_mode = 1;
-        a.solo = 0; // one arithmetic for early and late sectors: the fixed 16-lane grouping (records do not depend on eval_cap or timing)
-      }
       int rc = launch_starved(e, a, c, e->class_begin[c], st);
       if (rc)
         return rc;
-      if (use_ready) {
-        // the consumer: the class's lane-group kernel, bad pivots to the class's ill list; told to stop behind the
-        // starved-level launches (a one-thread kernel in stream order) - the regular pass takes what it left
-        consumer = a;
-        consumer.ready_mode = 2;
-        consumer.mid_state = e->d_mid.p;
-        consumer.ill_list = e->d_ill_list.p + e->class_begin[c];
-        consumer.ill_count = e->d_ill_count.p + c;
-        HIPCHK(lk_launch_solve(consumer, e->cfg.fitting_model, e->cfg.interpolation, 16, e->ready_stream[c]));
-        HIPCHK(hipEventRecord(e->ev_ready_join[c], e->ready_stream[c]));
-        HIPCHK(lk_launch_ready_stop(a.ready_ctr, st));
-        HIPCHK(hipStreamWaitEvent(st, e->ev_ready_join[c], 0));
-        a.ready_mode = 4; // the regular pass skips the sectors the consumer took
-      }
     }
     {
       int rc = launch_groups(e, a, kGroupOfClass[c], c, e->class_begin[c], st);
       if (rc)
         return rc;
-      a.ready_mode = 0;
     }
     if (team_done)
       HIPCHK(hipEventRecord(*team_done, st));

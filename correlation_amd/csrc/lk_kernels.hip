@@ -1613,9 +1613,7 @@ template <int P> __device__ __forceinline__ void translate(float (&p)[6], int sr
 // behind); then one wavefront per 64/GROUP sectors is launched and the hardware dispatcher
 // fills freed slots with whole wavefronts (measured on C2: 0.33 vs 0.37 ms).
 enum : int { PH_EVAL0 = 0, PH_TENT = 1, PH_REEVAL = 2, PH_FETCH = 3, PH_EXIT = 4 };
-constexpr int kStaleIterations = (int)0x80000000;
-// ready-list counters, each on a 128-byte line of its own (LkSolveArgs::ready_ctr, kLkReadyCtrWords words per class)
-enum : int { RC_PUBLISHED = 0, RC_TICKETS = 32, RC_STOP = 64 }; // marker in lk_result.iterations, see lk_stale_iterations_kernel
+constexpr int kStaleIterations = (int)0x80000000; // marker in lk_result.iterations, see lk_stale_iterations_kernel
 
 // Per-sector state that is only touched between evaluations ("cold": last-good parameters,
 // damping, counters, ...).  For the small lane groups it lives in LDS - every lane of a group
@@ -1796,24 +1794,6 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : THREA
     h.n_evals = k.n_evals;
     h.n_sample_evals = k.n_sample_evals;
     h.n_point_iters = k.n_point_iters;
-    h.early = 0;
-    if constexpr (STARVED) {
-      if (a.ready_mode == 1) {
-        // Publish: the record goes out with agent-scope stores (written through, visible to every XCD), drained,
-        // and only then the list entry - a consumer that sees the entry reads the record with agent-scope loads.
-        h.early = 1;
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(&h);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(a.handoff + k.s);
-#pragma unroll
-        for (int i = 0; i < (int)(sizeof(LkHandoff) / 4); ++i)
-          __hip_atomic_store(dst + i, w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t idx = __hip_atomic_fetch_add(a.ready_ctr + RC_PUBLISHED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.ready_list + idx, (uint32_t)k.s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        phase = PH_FETCH;
-        return;
-      }
-    }
     a.handoff[k.s] = h;
     phase = PH_FETCH;
   };
@@ -1873,8 +1853,6 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : THREA
     phase = PH_FETCH;
   };
   int steps = 0; // evaluations of the current sector in this kernel (STARVED: eval_cap)
-  constexpr bool READY_CONSUMER = GROUP == 16 && !SAFE && !REF; // the instance that may consume the ready list
-  int ready_ticket = -1, ready_spins = 0;
 
   auto finish_sector = [&](const Cold &k, const float (&evaluated)[6]) { // results of Newton_Raphson (:638-639, :848-870)
     if ((int)threadIdx.x % GROUP == 0 && team.rank == 0) {
@@ -1950,74 +1928,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : THREA
 #ifdef LK_TRACE_FINE
     const unsigned long long tr_f0 = __builtin_amdgcn_s_memtime();
 #endif
-    if constexpr (READY_CONSUMER) {
-      // Ready-list consumer (a.ready_mode 2 / 3): every row tries, once per step, to take the next published sector;
-      // a row that finds nothing stays in PH_FETCH and tries again (the other rows of the wavefront go on solving).
-      // (the rows of a wavefront fetch TOGETHER, when all of them are idle - like the aligned persistent launch: four
-      // sectors that start their remaining levels in step; a row that fetched on its own would hold its neighbours
-      // back at every level change - and one acquire serves the whole wavefront)
-      if (phase == PH_FETCH && a.ready_mode == 2 && __ballot(phase < PH_FETCH) == 0ull) {
-        const bool lead = ((int)threadIdx.x % GROUP) == 0;
-        const int lead_lane = ((int)threadIdx.x & 63) & ~(GROUP - 1);
-        uint32_t v = kLkReadyEmpty;
-        int verdict = 0; // 0: nothing yet (wait), 1: a sector (v), 2: told to stop
-        if (lead) {
-          // the stop word first: once the starved-level launches are over, the regular pass (the whole chip, adaptive
-          // scheduling) is the better place for whatever is left
-          if (__hip_atomic_load(a.ready_ctr + RC_STOP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || ++ready_spins > (1 << 14)) {
-            verdict = 2;
-          } else {
-            if (ready_ticket < 0)
-              ready_ticket = (int)__hip_atomic_fetch_add(a.ready_ctr + RC_TICKETS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ready_ticket < a.n_sectors)
-              v = __hip_atomic_load(a.ready_list + ready_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (v != kLkReadyEmpty) {
-              // mine: marked in the sector's hand-over record, which the regular pass behind us reads (it solves every
-              // early sector that is not marked)
-              __hip_atomic_store(&a.handoff[v].early, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              verdict = 1;
-            }
-          }
-        }
-        v = (uint32_t)__shfl((int)v, lead_lane, 64);
-        verdict = __shfl(verdict, lead_lane, 64);
-        if (__any(verdict == 1)) // ONE agent-scope acquire after the match: the records were written by other workgroups
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // (and their neighbours in the same cache line may sit stale in this XCD's L2)
-        if (verdict == 1) { // a sector: mine
-          ready_ticket = -1;
-          ready_spins = 0;
-          steps = 0;
-          Cold k{};
-          k.s = (int)v;
-          const float2 c0 = a.center[k.s];
-          k.c0x = c0.x;
-          k.c0y = c0.y;
-          k.use_saved = 1;
-          LkHandoff h;
-          {
-            uint32_t *w = reinterpret_cast<uint32_t *>(&h);
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(a.handoff + k.s);
-#pragma unroll
-            for (int i = 0; i < (int)(sizeof(LkHandoff) / 4); ++i)
-              w[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-#pragma unroll
-          for (int i = 0; i < 6; ++i)
-            p[i] = i < P ? h.p[i] : 0.f;
-          k.level = h.level;
-          k.level_old = h.level_old;
-          k.reached = h.reached;
-          k.n_evals = h.n_evals;
-          k.n_sample_evals = h.n_sample_evals;
-          k.n_point_iters = h.n_point_iters;
-          enter_level(k);
-          cold.store(cold_slot, k);
-        } else if (verdict == 2) {
-          phase = PH_EXIT; // nothing more will come (or the wait ran out)
-        }
-      }
-    }
-    if (phase == PH_FETCH && may_fetch && !(READY_CONSUMER && a.ready_mode == 2)) { // take the next sector
+    if (phase == PH_FETCH && may_fetch) { // take the next sector
       int slot = 0;
       // (lists of parked sectors: their length is read BEFORE the ticket is drawn - see the rewind below)
       const int n_parked = (finisher || a.resume) ? (int)*(const volatile uint32_t *)a.finish_count : 0;
@@ -2085,8 +1996,6 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : THREA
           k.n_evals = h.n_evals;
           k.n_sample_evals = h.n_sample_evals;
           k.n_point_iters = h.n_point_iters;
-          if (a.ready_mode == 4 && h.early == 2)
-            k.level = a.py_start - 1; // an early sector the ready-list consumer took
         } else {
 #pragma unroll
           for (int i = 0; i < 6; ++i)
@@ -2119,19 +2028,11 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : THREA
     } else {
       const unsigned long long act = __ballot(active);
       if (act == 0ull) {
-        // Rows still in PH_FETCH drew a sector that needed nothing (finished or taken by an earlier launch) or are
-        // waiting for the ready list: they fetch again.  Leaving here instead would be harmless for one wavefront -
-        // the others draw the remaining tickets - but when most sectors of a launch need nothing (the regular
-        // pass behind a ready-list consumer) every wavefront would leave within a few rounds and strand the rest.
-        if (__ballot(phase == PH_FETCH) != 0ull) {
-          if constexpr (READY_CONSUMER) {
-            if (a.ready_mode == 2) {
-              __builtin_amdgcn_s_sleep(127); // waiting for the producers: poll again in ~8 us
-              __builtin_amdgcn_s_sleep(127);
-            }
-          }
+        // Rows still in PH_FETCH drew a sector that needed nothing (finished by an earlier launch): they fetch again.
+        // Leaving here instead is harmless for one wavefront - the others draw the remaining tickets - but when most
+        // sectors of a launch need nothing, every wavefront would leave within a few rounds and strand the rest.
+        if (__ballot(phase == PH_FETCH) != 0ull)
           continue;
-        }
         break; // every group of this wavefront is out of work
       }
       if constexpr (GROUP == 32) {
@@ -3613,14 +3514,6 @@ hipError_t lk_launch_append_sector(const LkAppendArgs &a, hipStream_t st) {
   return hipGetLastError();
 }
 
-__global__ void lk_ready_stop_kernel(uint32_t *ctr) {
-  __hip_atomic_store(ctr + RC_STOP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-hipError_t lk_launch_ready_stop(uint32_t *ready_ctr, hipStream_t st) { // (stream-ordered behind the starved-level launches)
-  hipLaunchKernelGGL(lk_ready_stop_kernel, dim3(1), dim3(1), 0, st, ready_ctr);
-  return hipGetLastError();
-}
-
 hipError_t lk_launch_stale_iterations_blocks(lk_result *all, int n, int n_ranks, int cap, const int *carry_in, int *carry_out,
                                              hipStream_t st) {
   if (n <= 0)
@@ -3662,18 +3555,6 @@ static hipError_t launch_solve_gs(const LkSolveArgs &a, hipStream_t st) {
   b.persistent = force_persistent >= 0 ? force_persistent : (want > 2 * resident ? 1 : 0);
   if (GROUP == 1)
     b.persistent = 0; // every lane takes exactly one sector
-  if (GROUP == 16 && !SAFE && !REF && a.ready_mode == 2) {
-    // The ready-list consumer: tickets and the stop word live in ready_ctr.  It runs beside the starved-level
-    // launches and must leave them room: a quarter of what is resident (LK_OVERLAP_WAVES: tuning hook).
-    b.persistent = 1;
-    b.chunk = 0;
-    b.team_w = 0;
-    static const int cap_env = [] { const char *f = getenv("LK_OVERLAP_WAVES"); return f ? atoi(f) : 0; }();
-    const int cap = cap_env > 0 ? cap_env : resident / 4;
-    hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, GROUP, THREADS, SAFE, REF>), dim3((unsigned)(want < cap ? want : cap)),
-                       dim3(THREADS), 0, st, b);
-    return hipGetLastError();
-  }
   if (GROUP == 16 && SAFE && !REF && a.resume && !a.finisher) {
     // sectors parked with a bad pivot: normally none - a small grid that retires at once and
     // rewinds its own list and queue (they start at zero: lk_commit_sectors)

@@ -1736,20 +1736,3 @@ def test_kept_sums_save_evaluations_and_change_no_record(monkeypatch):
         assert saved > 0.08 * st0["evaluations"], (saved, st0["evaluations"])     # (config 4: 16 %)
         assert st1["evaluations"] >= st1["point_iterations"]                     # at least one evaluation per LM trip and level
 
-
-@pytest.mark.gpu
-def test_ready_list_overlap_gives_the_batch_invariant_records(tmp_path):
-    """LK_OVERLAP=1 (opt-in): sectors that are through their starved levels early are published by the one-lane kernel
-    and solved by a lane-group launch on a sibling stream WHILE the starved-level launches still run; the regular
-    pass takes what is left.  Whoever solves a sector uses the fixed 16-lane grouping, so the records must equal the
-    batch-invariant run's byte for byte and repeat from solve to solve (scripts/overlap_check.py spawns one process
-    per mode: the switch is read once per process)."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for wl_name in ("C4", "C4B"):
-        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "overlap_check.py"), wl_name], capture_output=True, text=True,
-                           timeout=600)
-        assert r.returncode == 0, r.stdout + r.stderr
-        assert "LK_OVERLAP=1: repeatable True" in r.stdout and "LK_OVERLAP=0: repeatable True" in r.stdout, r.stdout
-        assert "records differing between overlap off and on: 0 of" in r.stdout, r.stdout
