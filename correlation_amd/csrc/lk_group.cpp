@@ -129,15 +129,19 @@ struct lk_group {
     job = std::move(f);
     job_collective = collective;
     std::fill(rc.begin(), rc.end(), 0);
+    for (std::string &t : msg)
+      t.clear();
     pending = (int)m.size();
     ++gen;
     cv_job.notify_all();
     cv_done.wait(lock, [&] { return pending == 0; });
-    for (size_t i = 0; i < m.size(); ++i)
-      if (rc[i]) {
-        err = "rank " + std::to_string(i) + ": " + msg[i];
-        return rc[i];
-      }
+    // (a member that only relays the outcome of lk_group::agree has no message of its own: name the one that failed)
+    for (int pass = 0; pass < 2; ++pass)
+      for (size_t i = 0; i < m.size(); ++i)
+        if (rc[i] && (pass == 1 || !msg[i].empty())) {
+          err = "rank " + std::to_string(i) + ": " + msg[i];
+          return rc[i];
+        }
     return LK_ERROR_NONE;
   }
 };
@@ -577,6 +581,11 @@ int lk_group_correlate_all(lk_group *g, const float *guesses, lk_result *out) {
     int rc = [&]() -> int {
       if (!me.device_ok)
         return LK_ERROR_DEVICE;
+      if (const char *f = std::getenv("LK_GROUP_FAULT")) // test hook: this rank fails alone, before the collective
+        if (std::atoi(f) == me.rank) {
+          g->msg[(size_t)me.rank] = "LK_GROUP_FAULT: injected failure before the all-gather";
+          return LK_ERROR_DEVICE;
+        }
       if (guesses)
         GHIP(hipMemcpyAsync(me.d_guess, guesses + 6 * (size_t)me.first, 6 * (size_t)me.count * sizeof(float),
                             hipMemcpyHostToDevice, me.st));

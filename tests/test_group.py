@@ -162,6 +162,29 @@ def test_group_in_reference_order_mode_carries_the_stale_iteration_count_across_
 
 
 @pytest.mark.gpu
+def test_a_member_that_fails_alone_fails_the_call_instead_of_hanging_it(speckle512, monkeypatch):
+    """A member that fails before the all-gather (a deferred re-commit, an allocation, the guess upload; here the
+    LK_GROUP_FAULT hook) must make the CALL fail on every member - nobody enters the collective - and leave the group
+    usable: round 2's group returned early on that rank and left the others' collective waiting for ever."""
+    und, dfm = speckle512
+    g = ca.HipCorrelationGroup([0, 0, 0])
+    g.for_each_engine("lk_set_batch_invariant", 1)
+    g.set_image(ca.IMG_UND, und)
+    g.set_image(ca.IMG_DEF, dfm)
+    g.set_rect_grid(24.0, 24.0, 487.0, 487.0, 9, 8)
+    g.commit_sectors()
+    want = g.correlate_all(np.zeros(6, np.float32))
+    for rank in (1, 0, 2):
+        monkeypatch.setenv("LK_GROUP_FAULT", str(rank))
+        with pytest.raises(ca.LkError) as ei:
+            g.correlate_all(np.zeros(6, np.float32))
+        assert ei.value.code == ca.ERROR_DEVICE and f"rank {rank}" in str(ei.value)
+        monkeypatch.delenv("LK_GROUP_FAULT")
+        assert g.correlate_all(np.zeros(6, np.float32)).tobytes() == want.tobytes()      # the group is still usable
+    g.close()
+
+
+@pytest.mark.gpu
 def test_group_tracks_a_constant_velocity_sequence():
     """BASELINE config 4's shape: the guess history lives with the engine that owns the sector; per frame
     only the new image goes out and the records come back (und fixed, def <- nxt rotation)."""

@@ -1736,3 +1736,58 @@ def test_kept_sums_save_evaluations_and_change_no_record(monkeypatch):
         assert saved > 0.08 * st0["evaluations"], (saved, st0["evaluations"])     # (config 4: 16 %)
         assert st1["evaluations"] >= st1["point_iterations"]                     # at least one evaluation per LM trip and level
 
+
+
+@pytest.mark.gpu
+def test_sectors_appended_one_by_one_equal_the_full_commit(speckle512):
+    """lk_commit_sectors' append path (the reference's first-frame loop registers and solves sector after sector,
+    manager_class.cpp:304-460): rectangles of different sizes - incl. one with a starved coarsest level and one that
+    gets a whole wavefront - registered and committed one at a time, each solved on its own in between, must leave the
+    engine in the state a single commit of all of them gives: same batch records, same single-sector records; a
+    rectangle moved by lk_update_sector is patched in place; re-registering a committed sector falls back to the full
+    rebuild and keeps the others' sequence state."""
+    und, dfm = speckle512
+    rects = [(40, 40, 58, 58), (100, 60, 140, 90), (200, 200, 206, 206), (300, 100, 330, 160), (60, 300, 78, 318),
+             (150, 350, 168, 368), (400, 400, 440, 440), (260, 260, 278, 278)]
+
+    def engine():
+        e = ca.HipCorrelationEngine()
+        e.set_batch_invariant(True)
+        e.set_undeformed_image(und)
+        e.set_deformed_image(dfm)
+        return e
+    n = len(rects)
+    ref = engine()                                      # the same rectangles in ONE commit, plus an explicit list behind them
+    for s, r in enumerate(rects):
+        ref.resetPolygon_rect(s, *r)
+    ref.set_sector_points(n, np.float32([[10, 10], [11, 10], [10, 11], [11, 11], [12, 10], [12, 11]]))
+    ref.commit_sectors()
+    want_all = ref.correlate_all(np.zeros(6, np.float32))
+    want = want_all[:n]
+    e = engine()
+    singles = []
+    for s, r in enumerate(rects):
+        e.resetPolygon_rect(s, *r)
+        e.commit_sectors()                              # appends behind the committed ones (from the second on)
+        singles.append(e.correlate(s, np.zeros(6, np.float32))[0])
+    assert np.array(singles, dtype=want.dtype).tobytes() == want.tobytes()
+    got = e.correlate_all(np.zeros(6, np.float32))      # (the batch's size classes are analysed now)
+    assert got.tobytes() == want.tobytes()
+    assert [e.sector_info(s)[0] for s in range(n)] == [ref.sector_info(s)[0] for s in range(n)]
+    # Lagrangian move of every sector by its own record: patched in place here; on the reference engine the explicit list
+    # moves first, which sends every later update through the host records and a full rebuild before the next solve
+    for s in range(n):
+        e.update_sector(s, 1)
+    for s in [n] + list(range(n)):
+        ref.update_sector(s, 1)
+    a, b = e.correlate_all(want["p"]), ref.correlate_all(want_all["p"])
+    assert a.tobytes() == b[:n].tobytes()
+    assert np.abs(a["und_cx"] - want["und_cx"] - np.round(want["p"][:, 0])).max() <= 1.0
+    # a committed sector registered anew: full rebuild, its own state starts from zero, the others keep theirs
+    e.resetPolygon_rect(2, 210, 210, 216, 216)
+    e.commit_sectors()
+    c = e.correlate_all(want["p"])
+    keep = [s for s in range(n) if s != 2]
+    assert c[keep].tobytes() == a[keep].tobytes() and c[2]["und_cx"] == 213.0
+    e.close()
+    ref.close()
