@@ -69,6 +69,8 @@ struct LkSolveArgs {
   int safe;              // 1: reference-exact handling of starved / ill-conditioned levels
   int reference_order;   // T > 0 (SAFE 16- / 64-lane kernels): every level with the reference's summation order for
                          //   number_of_threads = T and its QR - bit-identical records (lk_set_reference_order)
+  int mark_stale;        // reference-order mode (any instance of its launch chain): a sector whose very first evaluation fails
+                         //   reports the stale-iteration marker instead of 0 (lk_stale_iterations_kernel resolves it)
   int persistent;        // 1: groups pull sectors from `queue`; 0: one sector per group by position
   int starved_max;       // a level with at most this many samples is "starved" (default 2 P)
   int keep_sums;         // 1 (default): a rejected trip continues from the kept sums of the last good parameters;

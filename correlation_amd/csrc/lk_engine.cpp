@@ -2117,6 +2117,25 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
       // ordered kernel is all of them.
       a.safe = 1;
       a.solo = 0;
+      // Starved levels (at most 2P samples) first, by the one-lane kernel and its finisher: their sums and their QR
+      // are the sequential reference's by construction, 64 sectors share one instruction stream of the QR instead of
+      // four, and the records stay the same bytes (config 5: the ordered kernel then starts at level 2).  Only for
+      // thread counts that leave such a level's summation sequential: T = 1, or T >= the level's sample count (every
+      // chunk is one sample then, correlation_class.cpp:169-186).
+      const char *chain_env = std::getenv("LK_REF_STARVED_CHAIN"); // test hook, read per call: 0 never, 2 whatever the sector count
+      const int ref_chain = chain_env ? std::atoi(chain_env) : 1;
+      // ... and only where the one-lane kernel has the wavefronts to fill the chip (64 sectors each): config 5's
+      // 199 809 sectors 10.0 -> 8.6 ms; config 4's 50 176 would be 784 wavefronts waiting on their own QR chains
+      // (2.12 -> 2.18 ms), so they stay with the ordered kernel.
+      if (ref_chain != 0 && e->class_starved[c] && e->eval_cap > 0 && (n >= 131072 || ref_chain == 2) &&
+          (e->reference_order == 1 || e->reference_order >= starved_max(e))) {
+        a.reference_order = 0; // (the starved-level instances; `mark_stale` keeps the stale-iteration markers coming)
+        a.mark_stale = 1;
+        int rc = launch_starved(e, a, c, e->class_begin[c], st);
+        if (rc)
+          return rc;
+      }
+      a.mark_stale = 1;
       a.reference_order = e->reference_order;
       HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, c == 0 ? 16 : 64, st));
       if (st != e->stream) {

@@ -1866,7 +1866,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : THREA
       // reference-order mode: the very first evaluation of the sector failed, so no LM trip ever ran -
       // the reference then reports whatever its reached_iterations member still holds from the sector
       // before (correlation_class.cpp:413-419, :870); lk_stale_iterations_kernel fills that in
-      r.iterations = (ordered_all && k.n_evals == 1u && k.error != LK_ERROR_NONE && k.lg_chi == FLT_MAX && k.reached == 0)
+      r.iterations = ((ordered_all || a.mark_stale != 0) && k.n_evals == 1u && k.error != LK_ERROR_NONE && k.lg_chi == FLT_MAX && k.reached == 0)
                          ? kStaleIterations
                          : k.reached;
       r.errorCode = k.error;

@@ -129,9 +129,9 @@ int lk_set_batch_invariant(lk_engine *e, int enabled);
  * thread count (T = 1: one running sum; the reference's compile-time default is 20, defines.hpp).  The records
  * are also independent of batch composition.  The sample work stays parallel (a 16-lane row or a
  * wavefront per sector forms the per-sample products and transposes them through LDS; only the
- * additions of each sum run as a chain), so the mode costs 1.4-2.7x the default's time (measured:
- * config 2 0.54-0.65 against 0.24 ms, config 4 3.2 against 1.9 ms, config 5 15 against 5.6 ms), not the
- * serial loop's.  threads = 0 (default): lane-parallel sums and the root-free Cholesky solve,
+ * additions of each sum run as a chain; the lanes of a wavefront are dealt to its four sectors by need), so the
+ * mode costs 1.1-1.9x the default's time (measured, round 3: config 2 0.46 against 0.24 ms, config 4 2.1 against
+ * 1.9 ms, config 5 8.6 against 5.4 ms), not the serial loop's.  threads = 0 (default): lane-parallel sums and the root-free Cholesky solve,
  * which differ from the reference by summation order and solver rounding only.
  * May be called at any time; the lane groups are re-chosen before the next solve. */
 int lk_set_reference_order(lk_engine *e, int threads);

@@ -127,10 +127,12 @@ def test_group_of_several_ranks_equals_the_engine(oracle, speckle512, n_ranks):
 
 
 @pytest.mark.gpu
-def test_group_in_reference_order_mode_carries_the_stale_iteration_count_across_shards(oracle, speckle512):
+@pytest.mark.parametrize("chain", ["0", "2"])
+def test_group_in_reference_order_mode_carries_the_stale_iteration_count_across_shards(oracle, speckle512, chain, monkeypatch):
     """Reference-order mode: a sector whose very first evaluation fails reports the iteration count the sector
     BEFORE it left behind (correlation_class.cpp:413-419, :870).  In a group the sector before the first one of
     a shard lives on another rank: the markers are resolved over the gathered records, in global order."""
+    monkeypatch.setenv("LK_REF_STARVED_CHAIN", chain)   # (2: starved levels by the one-lane kernel first - it must leave the markers too)
     und, dfm = speckle512
     bad = oracle.rect_points(0, 0, 20, 20)           # out of the image at evaluation #0 of the coarsest level
     good = [oracle.rect_points(60 + 40 * i, 80 + 30 * i, 90 + 40 * i, 105 + 30 * i) for i in range(9)]

@@ -273,7 +273,16 @@ def test_annular_and_blob_sectors_are_bit_identical(oracle):
     e.close()
 
 
-def test_config4_subset_is_bit_identical_including_nans(oracle):
+@pytest.fixture(params=["ordered kernel alone", "starved levels by the one-lane kernel and its finisher"])
+def starved_chain(request, monkeypatch):
+    """Reference-order mode solves starved levels either inside the ordered kernel or - classes of more than 131 072
+    sectors, i.e. config 5 at full size - by the one-lane kernel and its finisher first (LK_REF_STARVED_CHAIN: 0 never,
+    2 whatever the sector count).  Same bytes either way."""
+    monkeypatch.setenv("LK_REF_STARVED_CHAIN", "0" if request.param.startswith("ordered") else "2")
+    return request.param
+
+
+def test_config4_subset_is_bit_identical_including_nans(oracle, starved_chain):
     """3000 of BASELINE config 4's 7x7-sample sectors: levels 1 and 2 hold 9-16 and 1-4 samples for six
     parameters, the rank-revealing QR decides the steps, a few sectors end in max_iters or NaN
     parameters with error code 0 - whatever the oracle returns there, the engine returns the same bytes."""
@@ -297,7 +306,7 @@ def test_config4_subset_is_bit_identical_including_nans(oracle):
     e.close()
 
 
-def test_config5_subset_is_bit_identical(oracle):
+def test_config5_subset_is_bit_identical(oracle, starved_chain):
     """3000 sectors of BASELINE config 5's geometry (17x17 samples, 4 levels, 2x2..3x3 samples at level 3)
     on a 2048^2 stand-in of its 8192^2 pair (same sector grid pitch, same starved level)."""
     und, dfm = ca.speckle.speckle_pair(2048, 2048, p=(1.3, -0.7, 0.0005, 0.0, 0.0, -0.00025), seed=13)
@@ -318,7 +327,7 @@ def test_config5_subset_is_bit_identical(oracle):
     e.close()
 
 
-def test_error_paths_and_ragged_sectors_are_bit_identical(oracle, speckle512):
+def test_error_paths_and_ragged_sectors_are_bit_identical(oracle, speckle512, starved_chain):
     """Out-of-image at evaluation #0 and inside the loop, max_iters = 0, sectors of 1-5 samples,
     every model."""
     for model in (ca.FM_U, ca.FM_UV, ca.FM_UVQ, ca.FM_UVUXUYVXVY):
