@@ -925,9 +925,9 @@ __device__ __forceinline__ bool evaluate_ordered_flat(const LevelCtx &c, const f
     const int off1 = cnt[0], off2 = off1 + cnt[1], off3 = off2 + cnt[2], off4 = off3 + cnt[3]; // first tile row of sectors 1, 2, 3; rows in use
     int trips = 0x7fffffff; // every busy sector fills all its rows in each of them
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 4; ++r) // rem / cnt for cnt = 1 .. 4 without a division (at most 32 slots: 512 samples)
       if (cnt[r] > 0)
-        trips = min(trips, rem[r] / cnt[r]);
+        trips = min(trips, cnt[r] == 1 ? rem[r] : cnt[r] == 2 ? rem[r] >> 1 : cnt[r] == 3 ? (int)(((unsigned)rem[r] * 0xAAABu) >> 17) : rem[r] >> 2);
     // my tile row: its sector and its rank among the sector's rows; my home row: my own sector's run of tile rows
     const int my_sec = row >= off4 ? -1 : (row >= off1 ? 1 : 0) + (row >= off2 ? 1 : 0) + (row >= off3 ? 1 : 0);
     const int sec_off = my_sec == 1 ? off1 : my_sec == 2 ? off2 : my_sec == 3 ? off3 : 0;
