@@ -328,6 +328,7 @@ struct LevelCtx { // what a lane needs to know about its sector at the current l
   int n;
   int urows, ucols, drows, dcols;
   float cx, cy, scaling;
+  float inv_w; // 1 / rw (implicit rectangles: sample index -> row), once per level instead of once per evaluation
 };
 
 // sum inside each 16-lane row: every lane of the row ends with the same bits
@@ -474,7 +475,8 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
   // lane walks the samples in the REFERENCE's order and accumulates with a separate
   // multiply and add, exactly like interpolation_class.cpp:722-749, so A, b and chi are
   // bit-identical to the reference's.
-  const float inv_w = c.rw > 0 ? 1.f / (float)c.rw : 0.f;
+  // (16-lane rows divide here: one more live register per row would cost that kernel its fourth wavefront per SIMD)
+  const float inv_w = GROUP == 16 ? (c.rw > 0 ? 1.f / (float)c.rw : 0.f) : c.inv_w;
   const int rh = (GROUP == 1 && c.rw > 0) ? c.n / c.rw : 1; // height of the implicit rectangle
   for (int k = lane0; k < c.n; k += stride) {
     f32x2 q;
@@ -1629,11 +1631,23 @@ struct Cold {
   int sums_kept;  // the sums of the evaluation at lg_p are in the sector's cache (kernel instances with KEEP_SUMS)
 };
 constexpr int kColdWords = sizeof(Cold) / 4;
+static_assert(kColdWords % 4 == 2 && kColdWords + 7 <= kLkMidWords, "slot = 128-bit words + one 64-bit; the parked-sector record holds it");
 
-template <bool IN_LDS> struct ColdStore {
+// VEC: the slot moves as five 128-bit LDS accesses and a 64-bit one instead of 22 dwords, twice per step (32-lane groups: 32 instructions
+// fewer per step; the 16-lane kernel would pay for it with its fourth wavefront per SIMD - 135 VGPRs - and keeps dwords)
+template <bool IN_LDS, bool VEC = false> struct ColdStore {
   Cold reg;
   __device__ __forceinline__ Cold load(const uint32_t *slot) const {
-    if constexpr (IN_LDS) {
+    if constexpr (IN_LDS && VEC) {
+      Cold k;
+      uint4 *w = reinterpret_cast<uint4 *>(&k);
+      const uint4 *src = reinterpret_cast<const uint4 *>(slot); // (slots are 16-byte aligned)
+#pragma unroll
+      for (int i = 0; i < kColdWords / 4; ++i)
+        w[i] = src[i];
+      *reinterpret_cast<uint2 *>(w + kColdWords / 4) = *reinterpret_cast<const uint2 *>(src + kColdWords / 4);
+      return k;
+    } else if constexpr (IN_LDS) {
       Cold k;
       uint32_t *w = reinterpret_cast<uint32_t *>(&k);
 #pragma unroll
@@ -1645,7 +1659,14 @@ template <bool IN_LDS> struct ColdStore {
     }
   }
   __device__ __forceinline__ void store(uint32_t *slot, const Cold &k) {
-    if constexpr (IN_LDS) {
+    if constexpr (IN_LDS && VEC) {
+      const uint4 *w = reinterpret_cast<const uint4 *>(&k);
+      uint4 *dst = reinterpret_cast<uint4 *>(slot);
+#pragma unroll
+      for (int i = 0; i < kColdWords / 4; ++i)
+        dst[i] = w[i];
+      *reinterpret_cast<uint2 *>(dst + kColdWords / 4) = *reinterpret_cast<const uint2 *>(w + kColdWords / 4);
+    } else if constexpr (IN_LDS) {
       const uint32_t *w = reinterpret_cast<const uint32_t *>(&k);
 #pragma unroll
       for (int i = 0; i < kColdWords; ++i)
@@ -1670,7 +1691,7 @@ __device__ unsigned long long g_lk_trace[8 * 16384];
 // REF: the reference-order instances (lk_set_reference_order) - SAFE, one wavefront per workgroup, a 16-lane row
 // (four sectors per wavefront, lanes dealt by need: evaluate_ordered_flat) or a wavefront per sector.
 template <int MODEL, int INTERP, int GROUP, int THREADS, bool SAFE, bool REF = false>
-__global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : THREADS == 512 ? LK_MIN_WAVES_512 : 1)) lk_solve_kernel(LkSolveArgs a) {
+__global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAFE && !REF ? 4 : LK_MIN_WAVES) : THREADS == 512 ? LK_MIN_WAVES_512 : 1)) lk_solve_kernel(LkSolveArgs a) {
   static_assert(!REF || (SAFE && THREADS == kWave && (GROUP == 16 || GROUP == kWave)), "reference-order instances");
   constexpr int P = n_params(MODEL);
   using SumsT = Sums<P>;
@@ -1697,33 +1718,34 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : THREA
   // 35.7), same bits.  (After a sector changed hands in the middle of a level - parked and resumed by another
   // launch - the cache is empty and the first rejection takes the re-evaluation, as the large groups always do.)
   constexpr bool KEEP_SUMS = GROUP == 1 || GROUP == 16;
-  constexpr int kSlotWords = kColdWords + (KEEP_SUMS && COLD_IN_LDS ? SumsT::N : 0);
-  __shared__ uint32_t cold_lds[COLD_IN_LDS ? (THREADS / GROUP) * kSlotWords : 1];
+  constexpr int kSlotWordsRaw = kColdWords + (KEEP_SUMS && COLD_IN_LDS ? SumsT::N : 0);
+  constexpr int kSlotWords = GROUP == 32 ? (kSlotWordsRaw + 3) & ~3 : kSlotWordsRaw; // (128-bit accesses: 16-byte slots)
+  __shared__ __attribute__((aligned(16))) uint32_t cold_lds[COLD_IN_LDS ? (THREADS / GROUP) * kSlotWords : 4];
   uint32_t *cold_slot = cold_lds + (COLD_IN_LDS ? ((int)threadIdx.x / GROUP) * kSlotWords : 0);
-  ColdStore<COLD_IN_LDS> cold;
+  ColdStore<COLD_IN_LDS, GROUP == 32> cold;
   // (one lane per sector: a column of LDS per lane - 28 more registers would cost the kernel a wavefront per SIMD,
   // and config 5's 3100 wavefronts of it a second round)
   __shared__ float kept_lds[KEEP_SUMS && !COLD_IN_LDS ? SumsT::N * THREADS : 1];
   auto keep_sums = [&](const SumsT &v) {
-    if constexpr (KEEP_SUMS) {
+    if constexpr (KEEP_SUMS && COLD_IN_LDS) {
 #pragma unroll
-      for (int i = 0; i < SumsT::N; ++i) {
-        if constexpr (COLD_IN_LDS)
-          cold_slot[kColdWords + i] = __float_as_uint(v.v[i]);
-        else
-          kept_lds[i * THREADS + (int)threadIdx.x] = v.v[i];
-      }
+      for (int i = 0; i < SumsT::N; ++i)
+        cold_slot[kColdWords + i] = __float_as_uint(v.v[i]);
+    } else if constexpr (KEEP_SUMS) {
+#pragma unroll
+      for (int i = 0; i < SumsT::N; ++i)
+        kept_lds[i * THREADS + (int)threadIdx.x] = v.v[i];
     }
   };
   auto kept_sums = [&](SumsT &v) {
-    if constexpr (KEEP_SUMS) {
+    if constexpr (KEEP_SUMS && COLD_IN_LDS) {
 #pragma unroll
-      for (int i = 0; i < SumsT::N; ++i) {
-        if constexpr (COLD_IN_LDS)
-          v.v[i] = __uint_as_float(cold_slot[kColdWords + i]);
-        else
-          v.v[i] = kept_lds[i * THREADS + (int)threadIdx.x];
-      }
+      for (int i = 0; i < SumsT::N; ++i)
+        v.v[i] = __uint_as_float(cold_slot[kColdWords + i]);
+    } else if constexpr (KEEP_SUMS) {
+#pragma unroll
+      for (int i = 0; i < SumsT::N; ++i)
+        v.v[i] = kept_lds[i * THREADS + (int)threadIdx.x];
     }
   };
 
@@ -1815,6 +1837,8 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : THREA
     c.drows = lv.drows;
     c.dcols = lv.dcols;
     c.scaling = 1.f / ((float)c.n);
+    if constexpr (GROUP != 16)
+      c.inv_w = c.rw > 0 ? 1.f / (float)c.rw : 0.f;
     const float inv = 1.f / (float)(1 << k.level); // pyramid_class.cpp:357-361
     c.cx = k.level == 0 ? k.c0x : k.c0x * inv;
     c.cy = k.level == 0 ? k.c0y : k.c0y * inv;
@@ -2054,7 +2078,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : THREA
             take(p[i]);
           take(c.rx), take(c.ry), take(c.rw), take(c.n);
           take(c.urows), take(c.ucols), take(c.drows), take(c.dcols);
-          take(c.scaling), take(c.cx), take(c.cy);
+          take(c.scaling), take(c.cx), take(c.cy), take(c.inv_w);
           auto take_ptr = [&](auto &ptr) {
             unsigned long long bits = (unsigned long long)(uintptr_t)ptr;
             uint32_t lo32 = (uint32_t)bits, hi32 = (uint32_t)(bits >> 32);
@@ -2098,7 +2122,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? LK_MIN_WAVES : THREA
             take(p[i]);
           take(c.rx), take(c.ry), take(c.rw), take(c.n);
           take(c.urows), take(c.ucols), take(c.drows), take(c.dcols);
-          take(c.scaling), take(c.cx), take(c.cy);
+          take(c.scaling), take(c.cx), take(c.cy); // (c.inv_w: not used by 16-lane groups)
           auto take_ptr = [&](auto &ptr) {
             unsigned long long bits = (unsigned long long)(uintptr_t)ptr;
             uint32_t lo32 = (uint32_t)bits, hi32 = (uint32_t)(bits >> 32);
@@ -2418,6 +2442,7 @@ __global__ void __launch_bounds__(256) lk_eval_kernel(LkEvalArgs a) {
   c.dcols = lv.dcols;
   c.cx = a.level == 0 ? c0.x : c0.x * inv;
   c.cy = a.level == 0 ? c0.y : c0.y * inv;
+  c.inv_w = c.rw > 0 ? 1.f / (float)c.rw : 0.f;
   float p[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i)
