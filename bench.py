@@ -790,12 +790,18 @@ def main():
             }
             # the baseline doubles as a full-size parity sample
             xs = np.linspace(0, S - 1, min(args.cpu_sectors, S)).astype(np.int64)
+            rel_dchi = np.abs(res["chi"][xs] - res_1["chi"]) / np.abs(res_1["chi"])
+            same_it = res["iterations"][xs] == res_1["iterations"]
             line["parity_vs_cpu"] = {
                 "sectors": int(len(xs)),
                 "fast_mode": {
                     "max_abs_dp01": float(np.abs(res["p"][xs][:, :2] - res_1["p"][:, :2]).max()),
-                    "max_rel_dchi": float((np.abs(res["chi"][xs] - res_1["chi"]) / np.abs(res_1["chi"])).max()),
-                    "iterations_equal_fraction": float((res["iterations"][xs] == res_1["iterations"]).mean())},
+                    "max_rel_dchi": float(rel_dchi.max()),
+                    "iterations_equal_fraction": float(same_it.mean()),
+                    # north_star's "chi to 1e-5": how many sectors meet it in the default mode, and where the rest comes from
+                    "rel_dchi_p50": float(np.percentile(rel_dchi, 50)), "rel_dchi_p99": float(np.percentile(rel_dchi, 99)),
+                    "rel_dchi_le_1e-5_fraction": float((rel_dchi <= 1e-5).mean()),
+                    "max_rel_dchi_where_iterations_equal": float(rel_dchi[same_it].max()) if same_it.any() else None},
             }
             if res_ref is not None:
                 same = np.array([res_ref[i].tobytes() == res_1[j].tobytes() for j, i in enumerate(xs)])
