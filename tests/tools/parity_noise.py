@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import correlation_amd as ca  # noqa: E402
 from oracle import lk_oracle as lo  # noqa: E402
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000   # (LK_FORCE_SAFE / LK_FORCE_GROUP / LK_KEEP_SUMS in the environment: variants of the engine)
 und, dfm = ca.speckle.speckle_pair(2048, 2048, seed=7)
 e = ca.HipCorrelationEngine()
 e.set_undeformed_image(und)
@@ -37,10 +37,15 @@ def dev(a, b):
     d25 = np.abs(a["p"][:, 2:] - b["p"][:, 2:]).max(1)
     dchi = np.abs(a["chi"] - b["chi"]) / np.abs(b["chi"])
     q = lambda v: {k: float(np.quantile(v, x)) for k, x in (("p50", .5), ("p95", .95), ("p99", .99), ("max", 1.0))}
-    return {"iter_equal": float(same.mean()), "dp01_same_iter": q(d01[same]), "dp25_same_iter": q(d25[same]),
+    return {"iter_equal": float(same.mean()), "dchi_le_1e-5": float((dchi <= 1e-5).mean()), "dp01_same_iter": q(d01[same]), "dp25_same_iter": q(d25[same]),
             "dchi_same_iter": q(dchi[same]), "dp01_all": q(d01), "dchi_all": q(dchi)}
 
 
 out = {"gpu_vs_T1": dev(gpu[pick], res[1]), "T8_vs_T1": dev(res[8], res[1]), "T20_vs_T1": dev(res[20], res[1]),
        "gpu_vs_T20": dev(gpu[pick], res[20])}
-print(json.dumps(out, indent=1))
+if os.environ.get("LK_BRIEF"):
+    for k, v in out.items():
+        print(k, "iter_equal %.4f  dchi<=1e-5 %.4f  dchi p50 %.2e p99 %.2e max %.2e  dp01 p99 %.2e max %.2e"
+              % (v["iter_equal"], v["dchi_le_1e-5"], v["dchi_all"]["p50"], v["dchi_all"]["p99"], v["dchi_all"]["max"], v["dp01_all"]["p99"], v["dp01_all"]["max"]))
+else:
+    print(json.dumps(out, indent=1))
