@@ -86,6 +86,7 @@ SYMBOLS = {
     "lk_get_sector_info": (C.c_int, [_P, C.c_int, _I, _F, _F]),
     "lk_get_sector_level_count": (C.c_int, [_P, C.c_int, C.c_int, _I]),
     "lk_get_und_xy": (C.c_int, [_P, C.c_int, _F, C.c_int, _I]),
+    "lk_get_level_xy": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _F, C.c_int, _I]),
     "lk_get_def_xy": (C.c_int, [_P, C.c_int, _F, _F, C.c_int, _I]),
     "lk_correlate": (C.c_int, [_P, C.c_int, _F, _P]),
     "lk_correlate_all": (C.c_int, [_P, _F, _P]),

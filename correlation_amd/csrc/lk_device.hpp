@@ -11,6 +11,12 @@ struct LkLevelView {
   const uint8_t *und;  // undeformed image, level L
   const uint8_t *def;  // deformed image, level L
   const float2 *xy;    // concatenated per-sector sample lists of level L (AoS x,y)
+  const float2 *xy_eval; // the same lists with every sector's samples in row-major order (y outer, x inner), or null:
+                         //     what the lane groups of the default mode walk - neighbouring lanes then read neighbouring
+                         //     pixels of one image row.  The reference's order (x outer, y inner for annular sectors,
+                         //     manager_class.cpp:907-918) puts 64 consecutive samples on 64 image rows: 64 cache lines
+                         //     per load instruction.  Sums in the reference's order (starved levels, reference-order
+                         //     mode) and the centres use `xy`.
   const uint32_t *off; // [S+1] start of each sector's list in xy
   const int4 *rect;    // [S] implicit rectangular sectors: {x_first, y_first, width, n} at this
                        //     level (the same sample SET as manager_class.cpp:1607-1611 + the
@@ -29,6 +35,7 @@ struct LkHandoff {
   uint32_t n_evals, n_sample_evals, n_point_iters;
 };
 
+constexpr int kLkMaxTeam = 256; // workgroups per team at most (the kernel stages a team's partial sums in LDS: 32 floats each)
 constexpr int kLkMidWords = 32; // Cold (23) + p (6) + phase
 
 struct LkSolveArgs {

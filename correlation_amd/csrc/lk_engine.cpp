@@ -47,9 +47,9 @@ hipError_t lk_launch_decimate(const float2 *xy_prev, const uint32_t *off_prev, c
                               int level_delta, int n_sectors, uint32_t *pos, uint32_t *tiles, float2 *xy_out,
                               uint32_t *off_out, uint32_t *n_out, hipStream_t st);
 hipError_t lk_launch_roi_count(const LkRoiSector *sectors, const LkRoiFlat *flats, const uint32_t *tile_begin, int n_sectors,
-                               uint32_t n_tiles, uint32_t *tiles, uint32_t *n_out, hipStream_t st);
+                               uint32_t n_tiles, uint32_t *tiles, uint32_t *n_out, hipStream_t st, int rows = 0);
 hipError_t lk_launch_roi_fill(const LkRoiSector *sectors, const LkRoiFlat *flats, const uint32_t *tile_begin, int n_sectors,
-                              uint32_t n_tiles, const uint32_t *tiles, float2 *xy, uint32_t *off, hipStream_t st);
+                              uint32_t n_tiles, const uint32_t *tiles, float2 *xy, uint32_t *off, hipStream_t st, int rows = 0);
 hipError_t lk_launch_stale_iterations(lk_result *r, int n, const int *carry_in, int *carry_out, hipStream_t st);
 hipError_t lk_launch_append_sector(const LkAppendArgs &a, hipStream_t st);
 hipError_t lk_launch_mean_center(const float2 *xy, const uint32_t *off, int n_sectors, float2 *center, hipStream_t st);
@@ -239,6 +239,11 @@ struct lk_engine {
   int S = 0;
   std::vector<uint32_t> h_off[LK_MAX_LEVELS];
   DevBuf<float2> d_xy[LK_MAX_LEVELS];
+  // the row-major evaluation copy of the lists (LkLevelView::xy_eval; same offsets): built with the device ROI masks
+  // when the domain has annular sectors, dropped when the lists move (Lagrangian descriptions)
+  DevBuf<float2> d_xy_eval[LK_MAX_LEVELS];
+  DevBuf<uint32_t> d_off_eval;   // scratch: the offsets the second pass computes (equal to d_off)
+  bool eval_lists = false;
   DevBuf<uint32_t> d_off[LK_MAX_LEVELS];
   DevBuf<int4> d_rect[LK_MAX_LEVELS];
   std::vector<int4> h_rect[LK_MAX_LEVELS];
@@ -343,6 +348,7 @@ void lk_destroy(lk_engine *e) {
   e->d_lv.release();
   for (int l = 0; l < LK_MAX_LEVELS; ++l) {
     e->d_xy[l].release();
+    e->d_xy_eval[l].release();
     e->d_off[l].release();
     e->d_rect[l].release();
   }
@@ -997,7 +1003,7 @@ static int build_lists_roi_device(lk_engine *e, const std::vector<int> &levels) 
   if (!flats.empty())
     HIPCHK(hipMemcpyAsync(e->d_roi_flats.p, flats.data(), flats.size() * sizeof(LkRoiFlat), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(e->d_roi_tile_begin.p, tile_begin.data(), ((size_t)S + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-  HIPCHK(e->d_level_total.ensure(LK_MAX_LEVELS));
+  HIPCHK(e->d_level_total.ensure(2 * LK_MAX_LEVELS)); // (second half: scratch of the evaluation copy's passes)
   // (the tile table may be larger than the decimation's: both share d_tiles)
   HIPCHK(e->d_tiles.ensure(4 * (size_t)n_tiles + 2)); // (also enough for the decimation passes below in all but pathological blobs)
   HIPCHK(lk_launch_roi_count(e->d_roi_sectors.p, e->d_roi_flats.p, e->d_roi_tile_begin.p, S, n_tiles, e->d_tiles.p,
@@ -1039,6 +1045,31 @@ static int build_lists_roi_device(lk_engine *e, const std::vector<int> &levels) 
   else
     HIPCHK(lk_launch_mean_center(e->d_xy[0].p, e->d_off[0].p, S, e->d_center.p, st));
   HIPCHK(hipMemcpyAsync(e->h_center.data(), e->d_center.p, 2 * (size_t)S * sizeof(float), hipMemcpyDeviceToHost, st));
+  // The evaluation copy: the same masks walked row by row (only annular sectors come out in another order; a blob's
+  // scan lines are rows already), then the same decimation.  Same sample sets, hence the same offsets at every level.
+  e->eval_lists = false;
+  bool any_annular = false;
+  for (int s = 0; s < S; ++s)
+    any_annular = any_annular || e->hs[(size_t)s].lazy == 1;
+  const char *eval_flag = std::getenv("LK_EVAL_LISTS"); // test / tuning hook, read per commit
+  const bool eval_env = eval_flag ? std::atoi(eval_flag) != 0 : true;
+  if (any_annular && eval_env) {
+    HIPCHK(e->d_off_eval.ensure((size_t)S + 1));
+    uint32_t *totals = e->d_level_total.p + LK_MAX_LEVELS; // (scratch: the counts are the canonical lists')
+    for (int l : levels)
+      HIPCHK(e->d_xy_eval[l].ensure((size_t)total + 1));
+    HIPCHK(e->d_tiles.ensure(4 * (size_t)n_tiles + 2));
+    HIPCHK(lk_launch_roi_count(e->d_roi_sectors.p, e->d_roi_flats.p, e->d_roi_tile_begin.p, S, n_tiles, e->d_tiles.p, totals, st, 1));
+    HIPCHK(lk_launch_roi_fill(e->d_roi_sectors.p, e->d_roi_flats.p, e->d_roi_tile_begin.p, S, n_tiles, e->d_tiles.p,
+                              e->d_xy_eval[0].p, e->d_off_eval.p, st, 1));
+    HIPCHK(e->d_tiles.ensure((size_t)std::max<uint32_t>(n_tiles, (uint32_t)lk_decimate_tiles(total)) + 2));
+    for (size_t li = 1; li < levels.size(); ++li) {
+      const int l = levels[li], pl = levels[li - 1];
+      HIPCHK(lk_launch_decimate(e->d_xy_eval[pl].p, e->d_off[pl].p, e->d_level_total.p + pl, total, l - pl, S, e->d_pos.p,
+                                e->d_tiles.p, e->d_xy_eval[l].p, e->d_off_eval.p, totals + l, st));
+    }
+    e->eval_lists = true;
+  }
   HIPCHK(hipStreamSynchronize(st));
   for (int s = 0; s < S; ++s) {
     HostSector &h = e->hs[(size_t)s];
@@ -1124,7 +1155,10 @@ static int classify_sectors(lk_engine *e) {
       }
     if (n_team) {
       int w = force_team >= 1 ? force_team : (n0_max + kTeamMinSamples - 1) / kTeamMinSamples;
-      e->team_w = force_team == 1 ? 1 : std::min(std::max(w, 2), kMaxTeam); // the launch clamps it to what is resident
+      int max_team = kMaxTeam;
+      if (const char *f = std::getenv("LK_MAX_TEAM")) // tuning hook
+        max_team = std::min(std::max(2, std::atoi(f)), kLkMaxTeam);
+      e->team_w = force_team == 1 ? 1 : std::min(std::max(w, 2), max_team); // the launch clamps it to what is resident
       e->team_min_samples = force_team >= 1 ? 0 : kTeamMinSamples;
       HIPCHK(e->d_team_partials.ensure((size_t)n_team * 2 * (size_t)e->team_w * 32));
       HIPCHK(e->d_team_arrivals.ensure(2 * (size_t)n_team)); // arrival counters + broken flags
@@ -1185,6 +1219,7 @@ static int commit_impl(lk_engine *e, bool keep_state) {
     for (int s = 0; s < S; ++s)
       if (!e->hs[(size_t)s].is_rect && e->hs[(size_t)s].xy.empty())
         return e->fail(LK_ERROR_BAD_DOMAIN, "lk_commit_sectors: sector " + std::to_string(s) + " is empty");
+  e->eval_lists = false; // (only the device ROI path below builds the evaluation copy)
   if (device_roi) {
     int rc = build_lists_roi_device(e, levels);
     if (rc)
@@ -1652,6 +1687,7 @@ static int rewarp_on_device(lk_engine *e, const float *centers_xy, const float *
     e->backup_on_device = false;
   }
   e->h_center_prev = e->h_center;
+  e->eval_lists = false; // (the moved lists have no evaluation copy: the lane groups walk them in list order)
   for (HostSector &h : e->hs) // (descriptions of annular / blob sectors no longer describe the moved lists)
     h.lazy = 0;
   std::swap(e->d_xy[0], e->d_xy0_alt);
@@ -1862,6 +1898,29 @@ int lk_get_sector_level_count(lk_engine *e, int sector, int level, int *n) {
   return LK_ERROR_NONE;
 }
 
+int lk_get_level_xy(lk_engine *e, int level, int which, int sector, float *xy, int cap, int *count) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!e->committed || sector < 0 || sector >= e->S || level < 0 || level >= LK_MAX_LEVELS ||
+      e->h_off[level].size() != (size_t)e->S + 1)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_level_xy: unknown sector/level");
+  if (which != 0 && !e->eval_lists)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_level_xy: the domain has no evaluation copy of its lists");
+  const uint32_t b = e->h_off[level][(size_t)sector];
+  const uint32_t n = e->h_rect[level][(size_t)sector].z > 0 ? 0u : e->h_off[level][(size_t)sector + 1] - b;
+  if (count)
+    *count = (int)n;
+  if (xy && cap > 0 && n > 0) {
+    const float2 *src = which ? e->d_xy_eval[level].p : e->d_xy[level].p;
+    if (!src)
+      return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_level_xy: the lists of this level are not on the device");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(xy, src + b, sizeof(float2) * (size_t)std::min((int)n, cap), hipMemcpyDeviceToHost));
+  }
+  return LK_ERROR_NONE;
+}
+
 int lk_get_und_xy(lk_engine *e, int sector, float *xy, int cap, int *count) {
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
@@ -1948,6 +2007,7 @@ static int refresh_level_views(lk_engine *e) {
     v.und = u.lvl[l];
     v.def = d.lvl[l];
     v.xy = e->d_xy[l].p;
+    v.xy_eval = e->eval_lists ? e->d_xy_eval[l].p : nullptr;
     v.off = e->d_off[l].p;
     v.rect = e->d_rect[l].p;
     v.urows = u.rows >> l;

@@ -43,6 +43,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <type_traits>
 
 // Smallest pivot ratio d_j / A_jj the fast flavour factors through (below it the sector goes to
 // the SAFE kernel and the reference's QR).  1e-3 sent 0.4 % of config 4's solves there and, before
@@ -135,13 +136,8 @@ __device__ __forceinline__ Window4 load_window(gptr<uint8_t> def, int cols, int 
 // The 16 coefficients are produced exactly (see above) by 4 + 4 one-dimensional transforms, and
 // then W, dW/dx, dW/dy are accumulated in the reference's order (:94-126): three running sums,
 // jk outer / ik inner, each term built left to right.
-__device__ __forceinline__ void bicubic_sample(gptr<uint8_t> def, int cols, int ix, int iy, float dx,
-                                               float dy, float &W, float &Wx, float &Wy) {
-  gptr<uint8_t> base = def + (size_t)(iy - 1) * (size_t)cols + (size_t)(ix - 1);
-  uint32_t r0 = load_u32_unaligned(base);
-  uint32_t r1 = load_u32_unaligned(base + cols);
-  uint32_t r2 = load_u32_unaligned(base + 2 * (size_t)cols);
-  uint32_t r3 = load_u32_unaligned(base + 3 * (size_t)cols);
+__device__ __forceinline__ void bicubic_window(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, float dx, float dy,
+                                               float &W, float &Wx, float &Wy) {
   // t[r][k]: x-direction transform of image row r
   float t0[4], t1[4], t2[4], t3[4];
   cubic_1d(ub0(r0), ub1(r0), ub2(r0), ub3(r0), t0[0], t0[1], t0[2], t0[3]);
@@ -170,6 +166,12 @@ __device__ __forceinline__ void bicubic_sample(gptr<uint8_t> def, int cols, int 
         Wy += (float)jk * c * py[jk - 1] * px[ik];
     }
   }
+}
+
+__device__ __forceinline__ void bicubic_sample(gptr<uint8_t> def, int cols, int ix, int iy, float dx,
+                                               float dy, float &W, float &Wx, float &Wy) {
+  const Window4 w = load_window(def, cols, ix, iy);
+  bicubic_window(w.r0, w.r1, w.r2, w.r3, dx, dy, W, Wx, Wy);
 }
 
 // Catmull-Rom weights of the four samples at -1, 0, 1, 2 for position t in [0, 1) and their
@@ -478,6 +480,97 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
   // (16-lane rows divide here: one more live register per row would cost that kernel its fourth wavefront per SIMD)
   const float inv_w = GROUP == 16 ? (c.rw > 0 ? 1.f / (float)c.rw : 0.f) : c.inv_w;
   const int rh = (GROUP == 1 && c.rw > 0) ? c.n / c.rw : 1; // height of the implicit rectangle
+#ifndef LK_PIPE_MIN_GROUP // lane groups at least this wide prefetch the next sample (tuning hook)
+#define LK_PIPE_MIN_GROUP 256
+#endif
+  if constexpr (GROUP >= LK_PIPE_MIN_GROUP && INTERP == LK_IM_BICUBIC) {
+    // Software pipeline of the workgroup-wide groups (sectors of tens of thousands to millions of samples, explicit
+    // lists, two wavefronts per SIMD): the list entry, the coordinates and the five image loads of sample k + stride
+    // are issued before sample k's ~250 arithmetic instructions, so the two dependent load latencies of a trip
+    // (list -> window) overlap the previous trip's arithmetic.  The prefetch is branch-free - index and window position
+    // are clamped into range, the loads always happen - so that the compiler can wait for exactly the loads it needs
+    // (a conditional prefetch ends in `s_waitcnt vmcnt(0)` at the join and hides nothing).  Same operations on the same
+    // operands in the same order for every real sample: the results do not change.
+    struct Fetch {
+      Window4 w;
+      float und_w, fx, fy, dx, dy;
+      bool ok;
+    };
+    const int last = c.n - 1;
+    // (one loop per kind of sector, chosen outside: a list entry that merges with computed coordinates inside the loop
+    // has to have arrived at the merge, and the pipeline is gone)
+    auto run = [&](auto is_rect) {
+    constexpr bool RECT = decltype(is_rect)::value;
+    auto coords = [&](int k_in) -> f32x2 { // sample k of the sector (index clamped into the list)
+      const int k = min(k_in, last);
+      f32x2 q;
+      if constexpr (RECT) {
+        int row = (int)((float)k * inv_w);
+        int col = k - row * c.rw;
+        const int lo = col < 0 ? 1 : 0, hi = col >= c.rw ? 1 : 0;
+        col += (lo - hi) * c.rw;
+        row += hi - lo;
+        q.x = (float)(c.rx + col);
+        q.y = (float)(c.ry + row);
+      } else {
+        q = c.xy[k];
+      }
+      return q;
+    };
+    auto windows = [&](f32x2 q, Fetch &f) { // warp + the image loads of one sample
+      float xd, yd;
+      f.dx = 0.f, f.dy = 0.f;
+      Warp<MODEL>::apply(q.x, q.y, c.cx, c.cy, p, xd, yd, f.dx, f.dy);
+      int uix = (int)(q.x + 0.5f), uiy = (int)(q.y + 0.5f);
+      uix = min(max(uix, 0), umaxc);
+      uiy = min(max(uiy, 0), umaxr);
+      f.und_w = (float)c.und[(size_t)uiy * (size_t)c.ucols + (size_t)uix];
+      f.ok = xd > 1.f && yd > 1.f && xd < (float)c.dcols - 2.f && yd < (float)c.drows - 2.f; // sample_def's rule
+      const int ix = (int)xd, iy = (int)yd;
+      f.fx = xd - (float)ix + 1.f, f.fy = yd - (float)iy + 1.f;
+      f.w = load_window(c.def, c.dcols, min(max(ix, 1), c.dcols - 3), min(max(iy, 1), c.drows - 3)); // (ok: unclamped)
+    };
+    // two stages: the list entry of sample k + 2 stride is in flight while the window of k + stride is, and sample
+    // k is being computed
+    Fetch cur{};
+    f32x2 q1{};
+    if (c.n > 0) { // (same order of the loads as in the loop: list entry first, then the window of the sample before it)
+      const f32x2 q0 = coords(lane0);
+      q1 = coords(lane0 + stride);
+      windows(q0, cur);
+    }
+    for (int k = lane0; k < c.n; k += stride) {
+      const f32x2 q2 = coords(k + 2 * stride);
+      Fetch nxt;
+      windows(q1, nxt);
+      q1 = q2;
+      if (!cur.ok) {
+        bad = true; // the sums of an evaluation that hit the error are never used
+      } else {
+        float W, Wx, Wy;
+        bicubic_window(cur.w.r0, cur.w.r1, cur.w.r2, cur.w.r3, cur.fx, cur.fy, W, Wx, Wy);
+        const float V = cur.und_w - W;
+        float H[P];
+        Warp<MODEL>::jac(Wx, Wy, cur.dx, cur.dy, H);
+        int idx = 0;
+#pragma unroll
+        for (int p1 = 0; p1 < P; ++p1)
+#pragma unroll
+          for (int p2 = p1; p2 < P; ++p2)
+            S.v[idx] = __builtin_fmaf(H[p1], H[p2], S.v[idx]), ++idx;
+#pragma unroll
+        for (int p1 = 0; p1 < P; ++p1)
+          S.v[SumsT::NA + p1] = __builtin_fmaf(H[p1], V, S.v[SumsT::NA + p1]);
+        S.v[SumsT::N - 1] = __builtin_fmaf(V, V, S.v[SumsT::N - 1]);
+      }
+      cur = nxt;
+    }
+    };
+    if (c.rw > 0)
+      run(std::true_type{});
+    else
+      run(std::false_type{});
+  } else
   for (int k = lane0; k < c.n; k += stride) {
     f32x2 q;
     if (GROUP == 1 && c.rw > 0) { // reference order: x outer, y inner
@@ -650,32 +743,18 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
           __syncthreads();
           const bool timeout = lds[0] != 0.f;
           __syncthreads();
+          // The partials were written on other XCDs: a dependent chain of team_w remote loads per lane (the first
+          // version) cost 14-24 us per evaluation.  All 512 threads copy them into LDS first - every load in flight at
+          // once, one round trip - and then one lane per value adds them up in the same fixed order as before (config
+          // 3's blob, a team of 128: 0.75 -> 0.36 ms).
+          __shared__ float team_stage[kLkMaxTeam * 32];
+          for (int idx = (int)threadIdx.x; idx < team_w * 32; idx += GROUP)
+            team_stage[idx] = mine[idx];
+          __syncthreads();
           if ((int)threadIdx.x <= SumsT::N) { // one lane per value: fixed summation order
-            // (the partials come from other XCDs' L2s: sixteen - then four - loads in flight at a time instead of one
-            // round trip per workgroup of the team; the additions keep their order.  Config 3's blob, a team of 128:
-            // 0.75 -> 0.49 ms)
             float t = 0.f;
-            int w = 0;
-            for (; w + 16 <= team_w; w += 16) {
-              float v[16];
-#pragma unroll
-              for (int j = 0; j < 16; ++j)
-                v[j] = mine[(size_t)(w + j) * 32 + threadIdx.x];
-#pragma unroll
-              for (int j = 0; j < 16; ++j)
-                t += v[j];
-            }
-            for (; w + 4 <= team_w; w += 4) {
-              float v[4];
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-                v[j] = mine[(size_t)(w + j) * 32 + threadIdx.x];
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-                t += v[j];
-            }
-            for (; w < team_w; ++w)
-              t += mine[(size_t)w * 32 + threadIdx.x];
+            for (int w = 0; w < team_w; ++w)
+              t += team_stage[w * 32 + (int)threadIdx.x];
             lds[threadIdx.x] = t;
           }
           __syncthreads();
@@ -1853,7 +1932,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
     c.n = rc.z > 0 ? rc.w : (int)(lv.off[k.s + 1] - off);
     c.und = (gptr<uint8_t>)lv.und;
     c.def = (gptr<uint8_t>)lv.def;
-    c.xy = (gptr<f32x2>)(lv.xy + off);
+    c.xy = (gptr<f32x2>)((!starved && lv.xy_eval ? lv.xy_eval : lv.xy) + off); // (unordered sums: the row-major copy)
     c.urows = lv.urows;
     c.ucols = lv.ucols;
     c.drows = lv.drows;
@@ -2984,7 +3063,9 @@ __device__ __forceinline__ void roi_blob_row(const LkRoiSector &q, const LkRoiFl
 }
 
 // FILL = false: tile_count[t] = samples the tile keeps.  FILL = true: the samples, at tile_first[t].
-template <bool FILL>
+// ROWS: the candidates of an annular sector's bounding box are walked row by row (y outer, x inner) instead of the
+// reference's column by column - the evaluation copy of the lists (LkLevelView::xy_eval): same tiles, same samples.
+template <bool FILL, bool ROWS = false>
 __global__ void __launch_bounds__(kScanThreads) lk_roi_tile_kernel(const LkRoiSector *sectors, const LkRoiFlat *flats,
                                                                    const uint32_t *tile_begin, int n_sectors,
                                                                    uint32_t *tile_count, const uint32_t *tile_first,
@@ -3020,9 +3101,15 @@ __global__ void __launch_bounds__(kScanThreads) lk_roi_tile_kernel(const LkRoiSe
     fx[k] = 0.f;
     jj[k] = 0;
     if (idx < n_cand) {
-      const uint32_t col = idx / (uint32_t)h; // x outer, y inner
-      fx[k] = (float)(q.x0 + (int)col);
-      jj[k] = q.y0 + (int)(idx - col * (uint32_t)h);
+      if constexpr (ROWS) {
+        const uint32_t row = idx / (uint32_t)w; // y outer, x inner
+        fx[k] = (float)(q.x0 + (int)(idx - row * (uint32_t)w));
+        jj[k] = q.y0 + (int)row;
+      } else {
+        const uint32_t col = idx / (uint32_t)h; // x outer, y inner
+        fx[k] = (float)(q.x0 + (int)col);
+        jj[k] = q.y0 + (int)(idx - col * (uint32_t)h);
+      }
       keep[k] = roi_annular_keeps(q, fx[k], jj[k]);
     }
     cnt += keep[k];
@@ -3865,9 +3952,13 @@ static_assert(kLkRoiTile == kScanTile, "one ROI tile = one pass of the block sca
 
 // pass 1: per-tile counts -> exclusive prefix in place (tiles[n_tiles] = total, also *n_out)
 hipError_t lk_launch_roi_count(const LkRoiSector *sectors, const LkRoiFlat *flats, const uint32_t *tile_begin, int n_sectors,
-                               uint32_t n_tiles, uint32_t *tiles, uint32_t *n_out, hipStream_t st) {
+                               uint32_t n_tiles, uint32_t *tiles, uint32_t *n_out, hipStream_t st, int rows) {
   if (n_tiles == 0)
     return hipSuccess;
+  if (rows)
+    hipLaunchKernelGGL((lk_roi_tile_kernel<false, true>), dim3(n_tiles), dim3(kScanThreads), 0, st, sectors, flats, tile_begin,
+                       n_sectors, tiles, (const uint32_t *)nullptr, (float2 *)nullptr);
+  else
   hipLaunchKernelGGL(lk_roi_tile_kernel<false>, dim3(n_tiles), dim3(kScanThreads), 0, st, sectors, flats, tile_begin, n_sectors,
                      tiles, (const uint32_t *)nullptr, (float2 *)nullptr);
   hipLaunchKernelGGL(lk_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, tiles, (int)n_tiles, n_out);
@@ -3876,9 +3967,13 @@ hipError_t lk_launch_roi_count(const LkRoiSector *sectors, const LkRoiFlat *flat
 
 // pass 2: the samples and the per-sector offsets
 hipError_t lk_launch_roi_fill(const LkRoiSector *sectors, const LkRoiFlat *flats, const uint32_t *tile_begin, int n_sectors,
-                              uint32_t n_tiles, const uint32_t *tiles, float2 *xy, uint32_t *off, hipStream_t st) {
+                              uint32_t n_tiles, const uint32_t *tiles, float2 *xy, uint32_t *off, hipStream_t st, int rows) {
   if (n_tiles == 0)
     return hipSuccess;
+  if (rows)
+    hipLaunchKernelGGL((lk_roi_tile_kernel<true, true>), dim3(n_tiles), dim3(kScanThreads), 0, st, sectors, flats, tile_begin,
+                       n_sectors, (uint32_t *)nullptr, tiles, xy);
+  else
   hipLaunchKernelGGL(lk_roi_tile_kernel<true>, dim3(n_tiles), dim3(kScanThreads), 0, st, sectors, flats, tile_begin, n_sectors,
                      (uint32_t *)nullptr, tiles, xy);
   hipLaunchKernelGGL(lk_roi_offsets_kernel, dim3((unsigned)(n_sectors + 256) / 256), dim3(256), 0, st, tile_begin, tiles, n_sectors,

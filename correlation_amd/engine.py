@@ -202,6 +202,16 @@ class HipCorrelationEngine:
         self._chk(self.lib.lk_get_und_xy(self._h, sector, _ffi.fptr(out), n.value, C.byref(n)))
         return out
 
+    def level_xy(self, level, sector, evaluation_copy=False):
+        """the device's sample list of a sector at a pyramid level: the reference's order, or the row-major copy
+        the lane groups of the default mode walk (lk_get_level_xy)"""
+        n = C.c_int()
+        self._chk(self.lib.lk_get_level_xy(self._h, level, int(evaluation_copy), sector, None, 0, C.byref(n)))
+        out = np.empty((n.value, 2), np.float32)
+        if n.value:
+            self._chk(self.lib.lk_get_level_xy(self._h, level, int(evaluation_copy), sector, _ffi.fptr(out), n.value, C.byref(n)))
+        return out
+
     def getDefXY0ToCPU(self, sector, p):
         pp = np.zeros(6, np.float32)
         pp[:len(p)] = p

@@ -242,6 +242,12 @@ int lk_get_sector_level_count(lk_engine *e, int sector, int level, int *n);
 /* CudaClass::getUndXY0ToCPU / CorrelationClass::getUndXY0 (cuda_class.cu:607-609):
  * returns the count; copies min(count, cap) AoS pairs */
 int lk_get_und_xy(lk_engine *e, int sector, float *xy, int cap, int *count);
+/* Diagnostics: the explicit sample list of a sector at a pyramid level as the device holds it (pyramid_class.cpp:289-323:
+ * the decimated lists).  which = 0: the reference's order - what the centres, the starved levels and the reference-order
+ * mode walk.  which = 1: the row-major evaluation copy the lane groups of the default mode walk (annular sectors rasterised
+ * by the device masks; the same samples, y outer / x inner, so that neighbouring lanes read neighbouring pixels) -
+ * LK_ERROR_BAD_DOMAIN when the domain has none.  Implicit rectangles have no list (count 0). */
+int lk_get_level_xy(lk_engine *e, int level, int which, int sector, float *xy, int cap, int *count);
 /* CudaClass::getDefXY0ToCPU / CorrelationClass::getDefXY0 (cuda_class.cu:611-613,
  * kModel_inPlace correlationKernel.cu:56-110): level-0 samples warped by p */
 int lk_get_def_xy(lk_engine *e, int sector, const float *p, float *xy, int cap, int *count);

@@ -35,5 +35,15 @@ for _ in range(reps):
     e.correlate_all(g)
     ms.append(e.stats()["solve_ms"])
 st = e.stats()
+if os.environ.get("LK_TRACE_OUT"):   # a -DLK_TRACE tuning build (-D'LK_TRACE_PICK(G,S)=((G)==512)'): the per-workgroup trace of the last launch
+    import ctypes as C
+    lib = C.CDLL(ca.LIB_PATH)
+    buf = np.zeros(8 * 16384, np.uint64)
+    assert lib.lk_debug_trace(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
+    t = buf.reshape(-1, 8)
+    n = int(t[0, 3] >> 32)
+    t = t[:n].copy()
+    t[:, 3] &= 0xFFFFFFFF
+    np.savez_compressed(os.environ["LK_TRACE_OUT"], trace=t, solve_ms=st["solve_ms"], n_points=r["n_points"])
 print(f" sectors {len(r)} samples {int(r['n_points'].sum())} largest {int(r['n_points'].max())}  solve_ms min {min(ms):.4f} median {np.median(ms):.4f}  "
       f"evals/sector {st['evaluations'] / st['sectors']:.2f}  alg GB/s {st['algorithmic_bytes'] / (np.median(ms) * 1e-3) / 1e9:.1f}  errfree {(r['error_code'] == 0).mean():.4f}")

@@ -344,6 +344,7 @@ int lk_get_und_xy(lk_engine *e, int s, float *xy, int cap, int *count) {
     xy[2 * i] = v[2 * (size_t)i], xy[2 * i + 1] = v[2 * (size_t)i + 1];
   return 0;
 }
+int lk_get_level_xy(lk_engine *, int, int, int, float *, int, int *) { return LK_ERROR_BAD_DOMAIN; } // (no device lists here)
 int lk_get_def_xy(lk_engine *e, int s, const float *p, float *xy, int cap, int *count) {
   int rc = lk_get_und_xy(e, s, xy, cap, count);
   if (!rc && p)

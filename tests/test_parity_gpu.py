@@ -1616,6 +1616,9 @@ def test_device_roi_masks_equal_the_host_scans(oracle, monkeypatch):
     ann = [(np.float32(90.0 + i * dr), dr, np.float32(j) * da, da, 384.0, 380.0, as_) for i in range(rs) for j in range(as_)]
     ann.append((30.0, 55.0, 0.0, np.float32(2 * np.pi), 384.0, 384.0, 1))     # a full ring
 
+    monkeypatch.setenv("LK_EVAL_LISTS", "0")   # (records bit for bit: both paths walk the lists in the reference's order;
+    #                                               the row-major evaluation copy has its own test below)
+
     def build(host):
         monkeypatch.setenv("LK_HOST_ROI", "1" if host else "0")
         e = ca.HipCorrelationEngine(py_stop=3)
@@ -1660,6 +1663,60 @@ def test_device_roi_masks_equal_the_host_scans(oracle, monkeypatch):
         e.commit_sectors()
         assert np.array_equal(e.getUndXY0ToCPU(0), g[f"{name}_pts"].astype(np.float32)), name
     e.close()
+
+
+@pytest.mark.gpu
+def test_evaluation_copy_of_annular_lists_is_row_major_and_changes_only_the_summation_order(monkeypatch):
+    """Annular lists come in the reference's order, x outer / y inner (manager_class.cpp:907-918): 64 consecutive
+    samples lie on 64 image rows.  The lane groups of the default mode walk a second copy of every level's lists with
+    each sector's samples y outer / x inner (LkLevelView::xy_eval, built by the same device masks walked row by row and
+    the same decimation).  The copy must hold exactly the canonical list's samples, sorted by (y, x), at every level;
+    a blob's scan lines are rows already; centres, counts and the reference-order records do not depend on it; the
+    default mode's records move by summation-order noise only."""
+    und, dfm = ca.speckle.speckle_pair(768, 768, p=(0.9, 0.4, 0.001, 0.0005, -0.0005, 0.0015), seed=21)
+    rs, as_ = 3, 6
+    dr, da = np.float32((330.0 - 90.0) / rs), np.float32(2 * np.pi) / np.float32(as_)
+    t = 2 * np.pi * np.arange(24) / 24
+    blob = np.stack([384 + np.where(np.arange(24) % 2 == 0, 300.0, 180.0) * np.cos(t),
+                     384 + np.where(np.arange(24) % 2 == 0, 300.0, 180.0) * np.sin(t)], 1).astype(np.float32)
+
+    def run(flag, ref_order):
+        monkeypatch.setenv("LK_EVAL_LISTS", flag)
+        e = ca.HipCorrelationEngine(py_stop=2)
+        e.set_reference_order(ref_order)
+        e.set_undeformed_image(und)
+        e.set_deformed_image(dfm)
+        e.set_sectors_annular(0, np.float32([[np.float32(90.0 + i * dr), dr, np.float32(j) * da, da, 384.0, 380.0]
+                                             for i in range(rs) for j in range(as_)]), as_)
+        e.resetPolygon_blob(rs * as_, blob)
+        e.commit_sectors()
+        lists = None
+        if flag == "1" and not ref_order:
+            lists = [[(e.level_xy(l, k), e.level_xy(l, k, evaluation_copy=True)) for l in range(3)] for k in range(e.n_sectors)]
+        out = (e.correlate_all(np.zeros(6, np.float32)), [e.sector_info(k) for k in range(e.n_sectors)], lists)
+        e.close()
+        return out
+
+    r1, info1, lists = run("1", 0)
+    r0, info0, _ = run("0", 0)
+    assert info1 == info0                                   # counts and centres
+    moved = 0
+    for k, per_level in enumerate(lists):
+        for l, (canon, ev) in enumerate(per_level):
+            assert len(canon) == len(ev) and len(canon) > 0, (k, l)
+            if k == rs * as_:   # the blob: scan lines are rows already (flat triangle by flat triangle, polygon_class.cpp:389-391)
+                assert np.array_equal(canon, ev), l
+                continue
+            key = lambda a: a[:, 1].astype(np.int64) * 65536 + a[:, 0].astype(np.int64)
+            assert np.array_equal(np.sort(key(canon)), key(ev)), (k, l)      # the same samples, sorted by (y, x)
+            moved += int(not np.array_equal(canon, ev))
+    assert moved >= 3 * rs * as_ - 3                        # the annular sectors really come in another order
+    assert np.array_equal(r1["error_code"], r0["error_code"]) and (r1["error_code"] == 0).all()
+    assert np.abs(r1["p"][:, :2] - r0["p"][:, :2]).max() < 5e-4
+    assert (np.abs(r1["chi"] - r0["chi"]) / np.abs(r0["chi"])).max() < 3e-3
+    assert (r1["iterations"] == r0["iterations"]).mean() >= 0.9
+    # the reference-order mode walks the canonical lists: byte-identical records with and without the copy
+    assert run("1", 1)[0].tobytes() == run("0", 1)[0].tobytes()
 
 
 @pytest.mark.gpu
