@@ -83,6 +83,9 @@ struct LkSolveArgs {
   int keep_sums;         // 1 (default): a rejected trip continues from the kept sums of the last good parameters;
                          //   0 (LK_KEEP_SUMS=0, tests): it evaluates there again, as the reference does - same records
   int gpu_share;         // launches that may hold the GPU at the same time (>= 1): bounds a team launch's width
+  int slots_permille;    // 0: the launch may use every resident workgroup slot; else its share of them in 1/1000 - the
+                         //   team class and the one-workgroup class of one batch split the chip so that both are resident
+                         //   at once (a team launch: bounds its width; the one-workgroup class: a persistent grid of that size)
   int py_start, py_step, py_stop;
   float precision;
   int max_iters;

@@ -256,6 +256,7 @@ struct lk_engine {
   std::vector<uint32_t> h_order; // sectors grouped by size class
   int class_begin[kNumClasses + 1] = {0, 0, 0, 0, 0, 0, 0};
   bool class_starved[kNumClasses] = {false, false, false, false, false, false}; // a sector of the class has a starved level
+  int team_share_permille = 0; // > 0: the team class and the one-workgroup class of this domain split the resident slots (classify_sectors)
   bool force_safe = false; // LK_FORCE_SAFE: QR fallback for ill-conditioned systems in the lane-group kernels
   std::vector<int> h_class; // size class of every sector
   DevBuf<uint32_t> d_single, d_queue;
@@ -1173,6 +1174,31 @@ static int classify_sectors(lk_engine *e) {
         e->h_order.push_back((uint32_t)s);
   }
   e->class_begin[kNumClasses] = (int)e->h_order.size();
+  // A team launch needs all its workgroups resident at once, and the one-workgroup class (one 512-thread workgroup per
+  // sector, as many as there are CUs) would hold every slot until its first sectors are done: the two launches then run
+  // one after the other whatever the streams say (config 3: 256 annular sectors 0.42 ms + the blob's team 0.40 ms).
+  // Instead they split the slots by their share of the samples: the team gets its share (at least a quarter), the
+  // one-workgroup class a persistent grid on the rest with its largest sectors first in the queue.
+  e->team_share_permille = 0;
+  {
+    const int cb = kTeamClass - 1;
+    const int n_one = e->class_begin[cb + 1] - e->class_begin[cb], n_team = e->class_begin[kTeamClass + 1] - e->class_begin[kTeamClass];
+    const char *f = std::getenv("LK_TEAM_SHARE"); // tuning hook: permille of the slots for the team class (0: no split)
+    if (n_one > 0 && n_team > 0 && e->team_w > 1 && !e->batch_invariant && e->reference_order == 0 && !(f && std::atoi(f) == 0)) {
+      double s_one = 0, s_team = 0;
+      for (int s = 0; s < S; ++s) {
+        if (e->h_class[(size_t)s] == cb)
+          s_one += level0_count(e, s);
+        else if (e->h_class[(size_t)s] == kTeamClass)
+          s_team += level0_count(e, s);
+      }
+      // (the team is ONE critical path and pays its all-to-all per evaluation: a quarter more than its share of the samples)
+      int share = f ? std::atoi(f) : (int)(1250.0 * s_team / (s_team + s_one) + 0.5);
+      e->team_share_permille = std::min(std::max(share, 250), 750);
+      std::stable_sort(e->h_order.begin() + e->class_begin[cb], e->h_order.begin() + e->class_begin[cb + 1],
+                       [&](uint32_t x, uint32_t y) { return level0_count(e, (int)x) > level0_count(e, (int)y); });
+    }
+  }
   {
     int rc = refresh_starved(e);
     if (rc)
@@ -2207,6 +2233,8 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
     }
     std::unique_lock<std::mutex> team_turn;
     hipEvent_t *team_done = nullptr;
+    if (e->team_share_permille > 0 && (c == kTeamClass || c == kTeamClass - 1))
+      a.slots_permille = c == kTeamClass ? e->team_share_permille : 1000 - e->team_share_permille;
     if (c == kTeamClass) {
       a.team_w = e->team_w;
       a.team_min_samples = e->team_min_samples;

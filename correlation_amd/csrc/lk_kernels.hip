@@ -43,7 +43,6 @@
 #include <stdlib.h>
 
 #include <atomic>
-#include <type_traits>
 
 // Smallest pivot ratio d_j / A_jj the fast flavour factors through (below it the sector goes to
 // the SAFE kernel and the reference's QR).  1e-3 sent 0.4 % of config 4's solves there and, before
@@ -483,7 +482,7 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
 #ifndef LK_PIPE_MIN_GROUP // lane groups at least this wide prefetch the next sample (tuning hook)
 #define LK_PIPE_MIN_GROUP 256
 #endif
-  if constexpr (GROUP >= LK_PIPE_MIN_GROUP && INTERP == LK_IM_BICUBIC) {
+  if (GROUP >= LK_PIPE_MIN_GROUP && INTERP == LK_IM_BICUBIC && c.rw == 0) { // (explicit lists; implicit rectangles - config 1 - lose 6 % to it)
     // Software pipeline of the workgroup-wide groups (sectors of tens of thousands to millions of samples, explicit
     // lists, two wavefronts per SIMD): the list entry, the coordinates and the five image loads of sample k + stride
     // are issued before sample k's ~250 arithmetic instructions, so the two dependent load latencies of a trip
@@ -497,26 +496,9 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
       bool ok;
     };
     const int last = c.n - 1;
-    // (one loop per kind of sector, chosen outside: a list entry that merges with computed coordinates inside the loop
-    // has to have arrived at the merge, and the pipeline is gone)
-    auto run = [&](auto is_rect) {
-    constexpr bool RECT = decltype(is_rect)::value;
-    auto coords = [&](int k_in) -> f32x2 { // sample k of the sector (index clamped into the list)
-      const int k = min(k_in, last);
-      f32x2 q;
-      if constexpr (RECT) {
-        int row = (int)((float)k * inv_w);
-        int col = k - row * c.rw;
-        const int lo = col < 0 ? 1 : 0, hi = col >= c.rw ? 1 : 0;
-        col += (lo - hi) * c.rw;
-        row += hi - lo;
-        q.x = (float)(c.rx + col);
-        q.y = (float)(c.ry + row);
-      } else {
-        q = c.xy[k];
-      }
-      return q;
-    };
+    // (only explicit lists come here: a list entry that merges with computed coordinates inside the loop has to have
+    // arrived at the merge, and the pipeline is gone)
+    auto coords = [&](int k_in) -> f32x2 { return c.xy[min(k_in, last)]; }; // sample k of the sector (index clamped into the list)
     auto windows = [&](f32x2 q, Fetch &f) { // warp + the image loads of one sample
       float xd, yd;
       f.dx = 0.f, f.dy = 0.f;
@@ -565,11 +547,6 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
       }
       cur = nxt;
     }
-    };
-    if (c.rw > 0)
-      run(std::true_type{});
-    else
-      run(std::false_type{});
   } else
   for (int k = lane0; k < c.n; k += stride) {
     f32x2 q;
@@ -3671,6 +3648,12 @@ template <class K> static int resident_workgroups(K kernel, int threads) {
   return cus * per_cu;
 }
 
+// The team class's share of `all` workgroup slots (LkSolveArgs::slots_permille), in whole multiples of the 8 XCDs: workgroups
+// are dealt round-robin over the XCDs, one 512-thread workgroup fits a CU, and an XCD that got 33 workgroups for its 32 CUs
+// keeps one waiting - if that one belongs to the team, the team waits for a PERSISTENT workgroup of the other launch, i.e.
+// for that launch's end (measured on config 3: 0.61 ms with 96 + 160 workgroups, 0.98 with 108 + 147).
+static int split_slots(int all, int team_permille) { return (int)((long long)all * team_permille / 1000) & ~7; }
+
 template <int MODEL, int INTERP, int GROUP, int THREADS, bool SAFE, bool REF = false>
 static hipError_t launch_solve_gs(const LkSolveArgs &a, hipStream_t st) {
   static std::atomic<int> resident_cache{0}; // per template instance (one device type per process); engines launch from several threads
@@ -3714,7 +3697,9 @@ static hipError_t launch_solve_gs(const LkSolveArgs &a, hipStream_t st) {
   if (GROUP == 512 && a.team_w > 1) {
     // teams wait on each other: every workgroup of the launch must be resident at once - also
     // when other engines' team launches hold their share of the GPU (lk_set_pairs_in_flight)
-    const int share = resident / (a.gpu_share > 1 ? a.gpu_share : 1);
+    int share = resident / (a.gpu_share > 1 ? a.gpu_share : 1);
+    if (a.slots_permille > 0) // (the rest of the slots belongs to the one-workgroup class's launch on a sibling stream)
+      share = split_slots(share, a.slots_permille);
     b.team_w = a.team_w < share / a.n_sectors ? a.team_w : share / a.n_sectors;
     if (b.team_w > 1) {
       hipError_t te = hipMemsetAsync(a.team_arrivals, 0, 2 * (size_t)a.n_sectors * sizeof(uint32_t), st); // counters + broken flags
@@ -3729,12 +3714,21 @@ static hipError_t launch_solve_gs(const LkSolveArgs &a, hipStream_t st) {
   }
   b.team_w = 0;
   b.chunk = (want + 7) / 8;
+  int grid_persistent = resident;
+  if (GROUP == 512 && a.slots_permille > 0) {
+    // the one-workgroup class beside a team launch: a persistent grid on its share of the slots (largest sectors first in
+    // the queue, lk_engine.cpp), so that the team's workgroups are all resident next to it from the start
+    b.persistent = 1;
+    const int all = resident / (a.gpu_share > 1 ? a.gpu_share : 1);
+    const int share = (all & ~7) - split_slots(all, 1000 - a.slots_permille); // (what the team launch leaves, see split_slots)
+    grid_persistent = share < 1 ? 1 : (share < want ? share : want);
+  }
   if (b.persistent) { // rewind the sector queue
     hipError_t qe = hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st);
     if (qe != hipSuccess)
       return qe;
   }
-  dim3 grid((unsigned)(b.persistent ? resident : 8 * b.chunk));
+  dim3 grid((unsigned)(b.persistent ? grid_persistent : 8 * b.chunk));
   hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, GROUP, THREADS, SAFE, REF>), grid, dim3(THREADS), 0, st, b);
   return hipGetLastError();
 }
