@@ -243,6 +243,7 @@ struct lk_engine {
   // when the domain has annular sectors, dropped when the lists move (Lagrangian descriptions)
   DevBuf<float2> d_xy_eval[LK_MAX_LEVELS];
   DevBuf<uint32_t> d_off_eval;   // scratch: the offsets the second pass computes (equal to d_off)
+  DevBuf<float2> d_xy_eval0_alt; // level 0 of the copy while the lists move (lk_rewarp_sectors)
   bool eval_lists = false;
   DevBuf<uint32_t> d_off[LK_MAX_LEVELS];
   DevBuf<int4> d_rect[LK_MAX_LEVELS];
@@ -355,6 +356,8 @@ void lk_destroy(lk_engine *e) {
   }
   e->d_center.release();
   e->d_xy0_alt.release();
+  e->d_xy_eval0_alt.release();
+  e->d_off_eval.release();
   e->d_off0_alt.release();
   e->d_pos.release();
   e->d_tiles.release();
@@ -1704,6 +1707,15 @@ static int rewarp_on_device(lk_engine *e, const float *centers_xy, const float *
     a.offset = e->d_offsets.p;
   }
   HIPCHK(lk_launch_rewarp(a, cfg.fitting_model, st));
+  // the evaluation copy moves with the lists (sample by sample: it stays a permutation of them with the same offsets)
+  const bool keep_eval = e->eval_lists && explicit_already;
+  if (keep_eval) {
+    HIPCHK(e->d_xy_eval0_alt.ensure((size_t)total + 1));
+    LkRewarpArgs b = a;
+    b.src_xy = e->d_xy_eval[0].p;
+    b.dst_xy = e->d_xy_eval0_alt.p;
+    HIPCHK(lk_launch_rewarp(b, cfg.fitting_model, st));
+  }
   // what lk_restore_sectors needs: the previous lists stay in the alternate buffer when they
   // were device-built too, otherwise the host records are still good
   if (e->lists_on_device) {
@@ -1713,7 +1725,9 @@ static int rewarp_on_device(lk_engine *e, const float *centers_xy, const float *
     e->backup_on_device = false;
   }
   e->h_center_prev = e->h_center;
-  e->eval_lists = false; // (the moved lists have no evaluation copy: the lane groups walk them in list order)
+  e->eval_lists = false; // (until its coarser levels are rebuilt below)
+  if (keep_eval)
+    std::swap(e->d_xy_eval[0], e->d_xy_eval0_alt);
   for (HostSector &h : e->hs) // (descriptions of annular / blob sectors no longer describe the moved lists)
     h.lazy = 0;
   std::swap(e->d_xy[0], e->d_xy0_alt);
@@ -1724,7 +1738,7 @@ static int rewarp_on_device(lk_engine *e, const float *centers_xy, const float *
     HIPCHK(hipMemsetAsync(e->d_rect[l].p, 0, (size_t)S * sizeof(int4), st));
     e->h_rect[l].assign((size_t)S, make_int4(0, 0, 0, 0));
   }
-  HIPCHK(e->d_level_total.ensure(LK_MAX_LEVELS));
+  HIPCHK(e->d_level_total.ensure(2 * LK_MAX_LEVELS));
   HIPCHK(hipMemsetD32Async((hipDeviceptr_t)e->d_level_total.p, (int)total, 1, st));
   HIPCHK(e->d_pos.ensure((size_t)total + 1));
   HIPCHK(e->d_tiles.ensure((size_t)lk_decimate_tiles(total) + 2));
@@ -1736,6 +1750,16 @@ static int rewarp_on_device(lk_engine *e, const float *centers_xy, const float *
     e->h_off[l].resize((size_t)S + 1);
     HIPCHK(hipMemcpyAsync(e->h_off[l].data(), e->d_off[l].p, ((size_t)S + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost,
                           st));
+  }
+  if (keep_eval) { // the same decimation of the moved copy: the same sets, the offsets just computed
+    HIPCHK(e->d_off_eval.ensure((size_t)S + 1));
+    for (size_t li = 1; li < levels.size(); ++li) {
+      const int l = levels[li], pl = levels[li - 1];
+      HIPCHK(e->d_xy_eval[l].ensure((size_t)total + 1));
+      HIPCHK(lk_launch_decimate(e->d_xy_eval[pl].p, e->d_off[pl].p, e->d_level_total.p + pl, total, l - pl, S, e->d_pos.p,
+                                e->d_tiles.p, e->d_xy_eval[l].p, e->d_off_eval.p, e->d_level_total.p + LK_MAX_LEVELS + l, st));
+    }
+    e->eval_lists = true;
   }
   if (centers_xy) {
     e->h_center.assign(centers_xy, centers_xy + 2 * (size_t)S);

@@ -1693,12 +1693,17 @@ def test_evaluation_copy_of_annular_lists_is_row_major_and_changes_only_the_summ
         lists = None
         if flag == "1" and not ref_order:
             lists = [[(e.level_xy(l, k), e.level_xy(l, k, evaluation_copy=True)) for l in range(3)] for k in range(e.n_sectors)]
-        out = (e.correlate_all(np.zeros(6, np.float32)), [e.sector_info(k) for k in range(e.n_sectors)], lists)
+        out = [e.correlate_all(np.zeros(6, np.float32)), [e.sector_info(k) for k in range(e.n_sectors)], lists]
+        if not ref_order:   # the lists move with the last result (Lagrangian descriptions): the copy moves with them
+            e.rewarp_sectors()
+            if flag == "1":
+                out.append([[(e.level_xy(l, k), e.level_xy(l, k, evaluation_copy=True)) for l in range(3)] for k in range(e.n_sectors)])
+            out.append(e.correlate_all(np.zeros(6, np.float32)))
         e.close()
         return out
 
-    r1, info1, lists = run("1", 0)
-    r0, info0, _ = run("0", 0)
+    r1, info1, lists, moved_lists, m1 = run("1", 0)
+    r0, info0, _, m0 = run("0", 0)
     assert info1 == info0                                   # counts and centres
     moved = 0
     for k, per_level in enumerate(lists):
@@ -1715,6 +1720,15 @@ def test_evaluation_copy_of_annular_lists_is_row_major_and_changes_only_the_summ
     assert np.abs(r1["p"][:, :2] - r0["p"][:, :2]).max() < 5e-4
     assert (np.abs(r1["chi"] - r0["chi"]) / np.abs(r0["chi"])).max() < 3e-3
     assert (r1["iterations"] == r0["iterations"]).mean() >= 0.9
+    # moved lists: the copy is still the canonical list's samples (float coordinates now), annular sectors in another order
+    for k, per_level in enumerate(moved_lists):
+        for l, (canon, ev) in enumerate(per_level):
+            assert len(canon) == len(ev) and len(canon) > 0, (k, l)
+            assert np.array_equal(canon[np.lexsort((canon[:, 0], canon[:, 1]))], ev[np.lexsort((ev[:, 0], ev[:, 1]))]), (k, l)
+            assert k == rs * as_ or not np.array_equal(canon, ev), (k, l)
+    assert np.array_equal(m1["error_code"], m0["error_code"]) and (m1["error_code"] == 0).all()
+    assert np.abs(m1["p"][:, :2] - m0["p"][:, :2]).max() < 5e-4
+    assert (np.abs(m1["chi"] - m0["chi"]) / np.abs(m0["chi"])).max() < 3e-3
     # the reference-order mode walks the canonical lists: byte-identical records with and without the copy
     assert run("1", 1)[0].tobytes() == run("0", 1)[0].tobytes()
 
