@@ -330,8 +330,14 @@ def native_group_child(args, workload):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--native", "--gpus", str(args.gpus), "--workload", workload,
            "--steps", str(max(10, args.steps // 2)), "--warmup", str(max(3, args.warmup // 2))]
+    # (the child is its own single-process job: nothing of this process's torch.distributed.run environment may reach it -
+    # `--native` refuses WORLD_SIZE > 1, and a second process with the same RANK / MASTER_PORT has no business near the store)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK",
+                        "ROLE_WORLD_SIZE", "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "LK_BENCH_FORCE_DIST")
+           and not k.startswith(("TORCHELASTIC_", "TORCH_NCCL_", "NCCL_ASYNC"))}
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
         for ln in reversed(r.stdout.strip().splitlines()):
             if ln.startswith("{"):
                 d = json.loads(ln)

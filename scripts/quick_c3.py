@@ -13,6 +13,7 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 truth = (1.1, 0.6, 0.0008, 0.0004, -0.0004, 0.0012)
 und, dfm = ca.speckle.speckle_pair(4096, 4096, p=truth, seed=11, device="cuda")
 e = ca.HipCorrelationEngine(fitting_model=ca.FM_UVUXUYVXVY)
+e.set_reference_order(int(os.environ.get("LK_REF_ORDER", 0)))
 e.set_undeformed_image(und)
 e.set_deformed_image(dfm)
 rs, as_, ri, ro = 8, 32, 600.0, 1800.0

@@ -67,3 +67,32 @@ def test_committed_bench_lines_follow_the_contract(pattern, n1):
         lines = [ln for ln in open(f).read().splitlines() if ln.startswith("{")]
         assert len(lines) == 1, f
         check_line(json.loads(lines[0]), n1)
+
+
+def test_native_group_child_leaves_the_launcher_environment_behind(monkeypatch):
+    """`bench.py --gpus N` under torch.distributed.run starts `bench.py --native` (one process, all devices) as a child of
+    rank 0.  The child must not inherit the launcher's rendezvous variables: `--native` refuses WORLD_SIZE > 1, so with
+    them the block would read {"error": ...} in every run that has more than one rank - the runs it exists for."""
+    import argparse
+    import subprocess
+
+    import bench
+    seen = {}
+
+    def fake_run(cmd, **kw):
+        seen["cmd"], seen["env"] = cmd, kw.get("env")
+        line = {"value": 1.0, "ms_per_step": 1.0, "scaling": "strong", "config": {"workload": "C2", "parallelism": "lk_group", "n_ranks": 8},
+                "roofline": {"kernel_ms": 0.1}, "per_pair": {"error_free_fraction": 1.0}}
+        return subprocess.CompletedProcess(cmd, 0, stdout="noise\n" + json.dumps(line) + "\n", stderr="")
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    for k, v in (("WORLD_SIZE", "8"), ("RANK", "0"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29500"),
+                 ("TORCHELASTIC_RUN_ID", "x"), ("LK_BENCH_FORCE_DIST", "1"), ("HSA_ENABLE_IPC_MODE_LEGACY", "0")):
+        monkeypatch.setenv(k, v)
+    out = bench.native_group_child(argparse.Namespace(gpus=8, steps=20, warmup=5), "C2")
+    assert out["n_ranks"] == 8 and "error" not in out
+    env = seen["env"]
+    assert env is not None and env.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"      # (what RCCL needs stays)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "LK_BENCH_FORCE_DIST"):
+        assert k not in env, k
+    assert "--native" in seen["cmd"] and seen["cmd"][seen["cmd"].index("--gpus") + 1] == "8"
