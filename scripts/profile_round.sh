@@ -77,5 +77,6 @@ fi
 # the one-rank rehearsal of the multi-process bench (RCCL in the loop, every block of the N > 1 line)
 LK_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout -k 10 400 python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-other-configs > "$out/${tag}_bench_dist_rehearsal.json" 2> "$out/bench_dist.err"
 rm -rf "$out/c4" "$out"/pmc*/ "$out/trace" "$out"/*.npz
+scripts/profile_c3.sh "$tag" > /dev/null 2>&1   # config 3: <tag>_c3_steps.txt
 tail -1 "$out/${tag}_bench.json" | cut -c1-400
 cat "$out/${tag}_pmc_summary.txt"
