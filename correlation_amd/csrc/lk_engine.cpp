@@ -2247,7 +2247,11 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
       }
       a.mark_stale = 1;
       a.reference_order = e->reference_order;
-      HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, c == 0 ? 16 : 64, st));
+      // (a 16-lane row per small sector, a wavefront per larger one, a 512-thread workgroup per sector of the two big
+      // classes - and of the class below them while its sectors are no more than the CUs: a workgroup per sector then
+      // shortens every sector's chain, beyond that the wavefronts' throughput wins)
+      const int ref_group = c == 0 ? 16 : (c >= kTeamClass - 1 || (c == kTeamClass - 2 && n <= 256)) ? 512 : 64;
+      HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, ref_group, st));
       if (st != e->stream) {
         HIPCHK(hipEventRecord(e->ev_join[c], st));
         HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join[c], 0));

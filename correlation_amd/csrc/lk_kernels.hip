@@ -846,28 +846,46 @@ __device__ __forceinline__ bool evaluate_ordered(const LevelCtx &c, const float 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const float *r0 = mine + v0 * STR, *r1 = mine + v1 * STR;
+    // (a pass with no chunk boundary in it - all of them for T = 1, all but T of them on long lists - adds without looking)
+    if (CHUNKED && next_b < base + GROUP) {
 #pragma unroll
-    for (int j4 = 0; j4 < GROUP / 4; ++j4) {
-      const float4 a4 = *reinterpret_cast<const float4 *>(r0 + 4 * j4);
-      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if constexpr (TWO)
-        b4 = *reinterpret_cast<const float4 *>(r1 + 4 * j4);
-      const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (CHUNKED && base + 4 * j4 + j == next_b) { // a thread chunk ends before this sample (:253-275)
-          tot0 += acc0;
-          acc0 = 0.f;
-          if constexpr (TWO) {
-            tot1 += acc1;
-            acc1 = 0.f;
-          }
-          ++t_idx;
-          next_b += cq + (t_idx < cr ? 1 : 0);
-        }
-        acc0 += av[j];
+      for (int j4 = 0; j4 < GROUP / 4; ++j4) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(r0 + 4 * j4);
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (TWO)
-          acc1 += bv[j];
+          b4 = *reinterpret_cast<const float4 *>(r1 + 4 * j4);
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (base + 4 * j4 + j == next_b) { // a thread chunk ends before this sample (:253-275)
+            tot0 += acc0;
+            acc0 = 0.f;
+            if constexpr (TWO) {
+              tot1 += acc1;
+              acc1 = 0.f;
+            }
+            ++t_idx;
+            next_b += cq + (t_idx < cr ? 1 : 0);
+          }
+          acc0 += av[j];
+          if constexpr (TWO)
+            acc1 += bv[j];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j4 = 0; j4 < GROUP / 4; ++j4) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(r0 + 4 * j4);
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (TWO)
+          b4 = *reinterpret_cast<const float4 *>(r1 + 4 * j4);
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc0 += av[j];
+          if constexpr (TWO)
+            acc1 += bv[j];
+        }
       }
     }
   }
@@ -892,6 +910,138 @@ __device__ __forceinline__ bool evaluate_ordered(const LevelCtx &c, const float 
   if constexpr (GROUP == 16)
     return ((badmask >> (16 * (lane >> 4))) & 0xffffull) != 0ull;
   return badmask != 0ull;
+}
+
+// ------------------------------------------------------------------------------------
+// Reference-order evaluation of ONE big sector by a 512-thread workgroup (tens of thousands to millions of samples).
+//
+// One wavefront per sector (evaluate_ordered<GROUP = 64>) forms 64 products, then 28 of its lanes add them, then the
+// next 64: config 3's 4.2 M-sample blob took 35 ms per evaluation that way.  Here seven wavefronts FORM the products of
+// 448 consecutive samples per trip while the eighth ADDS the previous trip's - lane v owns sum v and walks the 448
+// products of its sum in sample order, with the thread-chunk boundaries of correlation_class.cpp:169-186,253-275 -
+// through two LDS tiles [sum][448] that swap roles at one workgroup barrier per trip.  The additions of one sum are a
+// single chain whoever forms the products (448 dependent additions per trip, about what seven wavefronts need for the
+// products), so this is the floor of the reference's order on one sector: ~10 ms per evaluation of the blob.
+// ord: 2 * N * kWgOrdStride floats.
+// ------------------------------------------------------------------------------------
+constexpr int kWgOrdSamples = 7 * kWave;          // samples per trip: seven producing wavefronts
+constexpr int kWgOrdStride = kWgOrdSamples + 4;   // (+4: the 128-bit reads of neighbouring owner lanes hit different banks)
+template <int N> constexpr int wg_ord_floats() { return 2 * N * kWgOrdStride; }
+
+template <int MODEL, int INTERP, bool CHUNKED>
+__device__ __forceinline__ bool evaluate_ordered_wg(const LevelCtx &c, const float (&p)[6], Sums<n_params(MODEL)> &S,
+                                                    float *ord, int threads) {
+  constexpr int P = n_params(MODEL);
+  using SumsT = Sums<P>;
+  constexpr int N = SumsT::N, STR = kWgOrdStride;
+  static_assert(N <= kWave, "one owner lane per sum");
+  const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & (kWave - 1);
+  const bool consumer = wave == 0;
+  const int v = lane < N ? lane : 0; // (idle lanes of the adding wavefront shadow sum 0)
+  float acc = 0.f, tot = 0.f;
+  const int T = CHUNKED ? (threads < 1 ? 1 : threads) : 1;
+  const int cq = c.n / T, cr = c.n - cq * T; // thread chunks of the reference: chunk t has n/T + (t < n%T) samples
+  int t_idx = 0, next_b = cq + (cr > 0 ? 1 : 0);
+  bool bad = false;
+  const int umaxr = c.urows - 1, umaxc = c.ucols - 1;
+  const int rh = c.rw > 0 ? c.n / c.rw : 1; // height of the implicit rectangle
+  const float inv_rh = 1.f / (float)rh;
+  const int n_trips = (c.n + kWgOrdSamples - 1) / kWgOrdSamples;
+  __syncthreads(); // (the previous evaluation's readers of the tiles are done)
+  for (int trip = 0; trip <= n_trips; ++trip) {
+    if (!consumer && trip < n_trips) { // products of this trip's samples -> tile[trip & 1]
+      float *tile = ord + (trip & 1) * (N * STR);
+      const int slot = (wave - 1) * kWave + lane, k = trip * kWgOrdSamples + slot;
+      float t[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        t[i] = 0.f;
+      if (k < c.n) {
+        f32x2 q;
+        if (c.rw > 0) { // x outer, y inner: k -> (column, row) of the rectangle
+          int col = (int)((float)k * inv_rh); // k / rh to within one unit below 2^23 samples, two below 2^25
+          int row = k - col * rh;
+#pragma unroll
+          for (int fix = 0; fix < 2; ++fix) {
+            const int lo = row < 0 ? 1 : 0, hi = row >= rh ? 1 : 0;
+            row += (lo - hi) * rh;
+            col += hi - lo;
+          }
+          q.x = (float)(c.rx + col);
+          q.y = (float)(c.ry + row);
+        } else {
+          q = c.xy[k];
+        }
+        float xd, yd, dx = 0.f, dy = 0.f;
+        Warp<MODEL>::apply(q.x, q.y, c.cx, c.cy, p, xd, yd, dx, dy);
+        int uix = (int)(q.x + 0.5f), uiy = (int)(q.y + 0.5f);
+        uix = min(max(uix, 0), umaxc);
+        uiy = min(max(uiy, 0), umaxr);
+        const float und_w = (float)c.und[(size_t)uiy * (size_t)c.ucols + (size_t)uix];
+        float W, Wx, Wy;
+        if (!sample_def<INTERP>(c.def, c.drows, c.dcols, xd, yd, W, Wx, Wy)) {
+          bad = true; // (the sums of an evaluation that hit the error are never used)
+        } else {
+          const float V = und_w - W;
+          float H[P];
+          Warp<MODEL>::jac(Wx, Wy, dx, dy, H);
+          int idx = 0;
+#pragma unroll
+          for (int p1 = 0; p1 < P; ++p1)
+#pragma unroll
+            for (int p2 = p1; p2 < P; ++p2)
+              t[idx++] = H[p1] * H[p2]; // rounded product; the rounded add is the adding wavefront's
+#pragma unroll
+          for (int p1 = 0; p1 < P; ++p1)
+            t[SumsT::NA + p1] = H[p1] * V;
+          t[N - 1] = V * V;
+        }
+      }
+      // (samples beyond the list leave +0: a sum that started at +0 is never -0, so adding +0 changes no bit)
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        tile[i * STR + slot] = t[i];
+    }
+    if (consumer && trip > 0) { // the previous trip's products, in sample order
+      const float *row = ord + ((trip - 1) & 1) * (N * STR) + v * STR;
+      const int base = (trip - 1) * kWgOrdSamples;
+      if (CHUNKED && next_b < base + kWgOrdSamples) { // a thread chunk ends inside this trip (:253-275): T trips per evaluation
+        for (int j4 = 0; j4 < kWgOrdSamples / 4; ++j4) {
+          const float4 a4 = *reinterpret_cast<const float4 *>(row + 4 * j4);
+          const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (base + 4 * j4 + j == next_b) {
+              tot += acc;
+              acc = 0.f;
+              ++t_idx;
+              next_b += cq + (t_idx < cr ? 1 : 0);
+            }
+            acc += av[j];
+          }
+        }
+      } else {
+#pragma unroll 4
+        for (int j4 = 0; j4 < kWgOrdSamples / 4; ++j4) {
+          const float4 a4 = *reinterpret_cast<const float4 *>(row + 4 * j4);
+          acc += a4.x;
+          acc += a4.y;
+          acc += a4.z;
+          acc += a4.w;
+        }
+      }
+    }
+    __syncthreads(); // the tiles swap roles
+  }
+  tot += acc; // the last chunk (T == 1: 0 + acc)
+  // totals and the error flag to every thread
+  if (consumer && lane < N)
+    ord[lane] = tot;
+  const bool any_bad = __syncthreads_or(bad ? 1 : 0) != 0; // (also: the totals are visible)
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    S.v[i] = ord[i];
+  return any_bad;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1770,7 +1920,7 @@ __device__ unsigned long long g_lk_trace[8 * 16384];
 // (four sectors per wavefront, lanes dealt by need: evaluate_ordered_flat) or a wavefront per sector.
 template <int MODEL, int INTERP, int GROUP, int THREADS, bool SAFE, bool REF = false>
 __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAFE && !REF ? 4 : LK_MIN_WAVES) : THREADS == 512 ? LK_MIN_WAVES_512 : 1)) lk_solve_kernel(LkSolveArgs a) {
-  static_assert(!REF || (SAFE && THREADS == kWave && (GROUP == 16 || GROUP == kWave)), "reference-order instances");
+  static_assert(!REF || (SAFE && ((THREADS == kWave && (GROUP == 16 || GROUP == kWave)) || (THREADS == 512 && GROUP == 512))), "reference-order instances");
   constexpr int P = n_params(MODEL);
   using SumsT = Sums<P>;
   constexpr bool COLD_IN_LDS = GROUP > 1 && GROUP <= kWave;
@@ -1786,7 +1936,8 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
   constexpr int RED_WORDS = GROUP > kWave ? (THREADS / kWave) * (SumsT::N + 1) + 1 : 1;
   __shared__ float lds[RED_WORDS];
   constexpr bool FLAT = REF && GROUP == 16; // four sectors per wavefront, lanes dealt by need
-  __shared__ __attribute__((aligned(16))) float ord_lds[FLAT ? flat_tile_floats<SumsT::N>() : ORD ? ord_floats<SumsT::N, ORD ? GROUP : 16>() : 4];
+  constexpr bool ORD_WG = REF && GROUP == 512; // one big sector per 512-thread workgroup: seven wavefronts form the products, one adds
+  __shared__ __attribute__((aligned(16))) float ord_lds[FLAT ? flat_tile_floats<SumsT::N>() : ORD_WG ? wg_ord_floats<SumsT::N>() : ORD ? ord_floats<SumsT::N, (ORD && !ORD_WG) ? GROUP : 16>() : 4];
   __shared__ __attribute__((aligned(16))) OrdCtx ord_ctx[FLAT ? 4 : 1];
   // The sums of the last ACCEPTED evaluation stay with the sector (small groups: behind its cold state in LDS; one
   // lane per sector: in registers).  A rejected trip continues from the last good parameters with a larger lambda;
@@ -2244,6 +2395,9 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
     if constexpr (FLAT) {
       err = a.reference_order > 1 ? evaluate_ordered_flat<MODEL, INTERP, true>(ce, p, S, ord_lds, ord_ctx, a.reference_order)
                                   : evaluate_ordered_flat<MODEL, INTERP, false>(ce, p, S, ord_lds, ord_ctx, 1);
+    } else if constexpr (ORD_WG) {
+      err = a.reference_order > 1 ? evaluate_ordered_wg<MODEL, INTERP, true>(ce, p, S, ord_lds, a.reference_order)
+                                  : evaluate_ordered_wg<MODEL, INTERP, false>(ce, p, S, ord_lds, 1);
     } else if constexpr (ORD) {
       err = a.reference_order > 1 ? evaluate_ordered<MODEL, INTERP, GROUP, true>(ce, p, S, ord_lds, a.reference_order)
                                   : evaluate_ordered<MODEL, INTERP, GROUP, false>(ce, p, S, ord_lds, 1);
@@ -3739,7 +3893,7 @@ static hipError_t launch_solve_gs(const LkSolveArgs &a, hipStream_t st) {
 // the GROUP == 1 kernel solves them first.
 template <int MODEL, int INTERP, int GROUP, int THREADS>
 static hipError_t launch_solve_g(const LkSolveArgs &a, hipStream_t st) {
-  if constexpr (THREADS == kWave && (GROUP == 16 || GROUP == kWave)) {
+  if constexpr ((THREADS == kWave && (GROUP == 16 || GROUP == kWave)) || (THREADS == 512 && GROUP == 512)) {
     if (a.reference_order > 0) // the reference-order instances
       return launch_solve_gs<MODEL, INTERP, GROUP, THREADS, true, true>(a, st);
   }

@@ -241,11 +241,14 @@ def test_switching_modes_on_a_committed_engine(oracle, speckle512):
     e.close()
 
 
-def test_annular_and_blob_sectors_are_bit_identical(oracle):
+@pytest.mark.parametrize("threads", [1, 7, 20])
+def test_annular_and_blob_sectors_are_bit_identical(oracle, threads):
     """Explicit sample lists (annular wedges, a full ring, a star-shaped blob; 2.6 k - 150 k samples),
-    centre = the float mean of the samples."""
+    centre = the float mean of the samples.  The larger sectors go through the workgroup-wide ordered evaluation
+    (seven wavefronts form the products, one adds them: evaluate_ordered_wg), the blob's 150 k samples in 335 trips;
+    the thread chunks of the reference (number_of_threads = 7: ragged chunks, 20: its default) end inside the trips."""
     und, dfm = ca.speckle.speckle_pair(768, 768, p=(0.9, 0.4, 0.001, 0.0005, -0.0005, 0.0015), seed=21)
-    e, o = engine_and_oracle(oracle, (und, dfm))
+    e, o = engine_and_oracle(oracle, (und, dfm), threads=threads)
     lists = []
     rs, as_ = 2, 4
     ri, ro, cx, cy = 120.0, 330.0, 384.0, 384.0
