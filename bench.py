@@ -221,6 +221,12 @@ def other_configs(ca):
         m["nan_records"] = int(np.isnan(r["p"]).any(1).sum())
         m["largest_sector_samples"] = int(r["n_points"].max())
         m["workload"] = "C3: 4096x4096, 8x32 annular sectors + one 64-vertex blob, affine, pyramid 0/1/2"
+        e.set_reference_order(1)
+        _, mr = timed(e, n=2)
+        m["reference_order_mode"] = {"solve_ms": mr["solve_ms"], "frac_of_hbm_peak": mr["algorithmic_GBps"] / HBM_PEAK_GBS,
+                                     "note": "a 512-thread workgroup per big sector (seven wavefronts form the products, one adds them in "
+                                             "sample order); the blob's 4.2 M samples are ONE chain of dependent additions per sum and "
+                                             "evaluation - that chain is this time"}
         out["C3"] = m
         e.close()
     except Exception as ex:
