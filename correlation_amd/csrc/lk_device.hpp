@@ -124,6 +124,7 @@ struct LkRewarpArgs { // level-0 sample lists moved by the last level-0 evaluati
   const float2 *offset;    // [S] Lagrangian description: samples move by add_pair(offset) instead of the warp
   int n_sectors;
   uint32_t total;          // dst_off[S]
+  int rows;                // 1: an implicit rectangle is walked row by row (y outer, x inner) - the evaluation copy of the lists
 };
 
 // One rectangular sector appended behind the committed ones (lk_commit_sectors' fast path): everything the

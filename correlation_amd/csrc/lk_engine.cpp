@@ -431,6 +431,7 @@ int lk_set_batch_invariant(lk_engine *e, int enabled) {
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
   e->batch_invariant = enabled != 0;
+  e->lv_dirty = true; // (which copy of the lists the lane groups walk)
   return LK_ERROR_NONE;
 }
 
@@ -1707,13 +1708,20 @@ static int rewarp_on_device(lk_engine *e, const float *centers_xy, const float *
     a.offset = e->d_offsets.p;
   }
   HIPCHK(lk_launch_rewarp(a, cfg.fitting_model, st));
-  // the evaluation copy moves with the lists (sample by sample: it stays a permutation of them with the same offsets)
-  const bool keep_eval = e->eval_lists && explicit_already;
+  // The evaluation copy moves with the lists (sample by sample: it stays a permutation of them with the same offsets);
+  // an implicit rectangle that becomes a list here gets one - its samples row by row, where the list proper has the
+  // reference's x outer / y inner (a 19 x 19 sector: 32 consecutive samples on 19 image rows instead of 2).
+  bool any_rect = false;
+  for (int s = 0; s < S; ++s)
+    any_rect = any_rect || e->h_rect[0][(size_t)s].z > 0;
+  const char *eval_flag = std::getenv("LK_EVAL_LISTS"); // test / tuning hook, read per call
+  const bool keep_eval = (e->eval_lists || any_rect) && !(eval_flag && std::atoi(eval_flag) == 0);
   if (keep_eval) {
     HIPCHK(e->d_xy_eval0_alt.ensure((size_t)total + 1));
     LkRewarpArgs b = a;
-    b.src_xy = e->d_xy_eval[0].p;
+    b.src_xy = e->eval_lists ? e->d_xy_eval[0].p : e->d_xy[0].p; // (explicit sectors of a mixed domain without a copy: list order)
     b.dst_xy = e->d_xy_eval0_alt.p;
+    b.rows = 1;
     HIPCHK(lk_launch_rewarp(b, cfg.fitting_model, st));
   }
   // what lk_restore_sectors needs: the previous lists stay in the alternate buffer when they
@@ -2057,7 +2065,9 @@ static int refresh_level_views(lk_engine *e) {
     v.und = u.lvl[l];
     v.def = d.lvl[l];
     v.xy = e->d_xy[l].p;
-    v.xy_eval = e->eval_lists ? e->d_xy_eval[l].p : nullptr;
+    // (batch-invariant mode: a sector's arithmetic must not depend on HOW its list was built - device masks and moved
+    // lists have the row-major copy, lists that came from the host do not - so every path walks the reference's order)
+    v.xy_eval = e->eval_lists && !e->batch_invariant ? e->d_xy_eval[l].p : nullptr;
     v.off = e->d_off[l].p;
     v.rect = e->d_rect[l].p;
     v.urows = u.rows >> l;

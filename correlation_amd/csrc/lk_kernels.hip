@@ -3032,7 +3032,11 @@ template <int MODEL> __global__ void lk_rewarp_kernel(LkRewarpArgs a) {
   const uint32_t k = i - a.dst_off[s];
   const int4 rc = a.src_rect[s];
   float2 q;
-  if (rc.z > 0) { // x outer, y inner (manager_class.cpp:1607-1611)
+  if (rc.z > 0 && a.rows) { // the evaluation copy: y outer, x inner (LkLevelView::xy_eval)
+    const int row = (int)k / rc.z;
+    q.x = (float)(rc.x + ((int)k - row * rc.z));
+    q.y = (float)(rc.y + row);
+  } else if (rc.z > 0) { // x outer, y inner (manager_class.cpp:1607-1611)
     const int h = rc.w / rc.z, col = (int)k / h;
     q.x = (float)(rc.x + col);
     q.y = (float)(rc.y + ((int)k - col * h));

@@ -1010,6 +1010,7 @@ def test_device_rebuilt_lists_equal_the_host_rebuild(monkeypatch, given_centers,
     restated reference loop.  Lists, centres, per-level counts and the next solve's records must
     be the same bits - over two moves and a partial restore."""
     frames = ca.speckle.speckle_sequence(320, 288, 3, velocity=(0.7, -0.4), dilation=6e-4, seed=9)
+    monkeypatch.setenv("LK_EVAL_LISTS", "0")   # (records bit for bit: the host rebuild has the lists in the reference's order only)
 
     def oracle_free_rect(x0, y0, x1, y1):   # the samples of a rectangle as an explicit list, x outer / y inner
         xs, ys = np.meshgrid(np.arange(x0, x1 + 1), np.arange(y0, y1 + 1), indexing="ij")
@@ -1169,6 +1170,8 @@ def test_update_sector_equals_the_frame_loop(mode):
 
     def setup():
         e = ca.HipCorrelationEngine(fitting_model=model)
+        e.set_batch_invariant(True)   # (bit for bit: the frame loop moves its lists on the device, with their row-major
+        #                                evaluation copy; the per-sector path re-commits host lists, which have none)
         e.set_undeformed_image(frames[0])
         e.set_deformed_image(frames[1])
         return e
@@ -1731,6 +1734,48 @@ def test_evaluation_copy_of_annular_lists_is_row_major_and_changes_only_the_summ
     assert (np.abs(m1["chi"] - m0["chi"]) / np.abs(m0["chi"])).max() < 3e-3
     # the reference-order mode walks the canonical lists: byte-identical records with and without the copy
     assert run("1", 1)[0].tobytes() == run("0", 1)[0].tobytes()
+
+
+@pytest.mark.gpu
+def test_rectangles_that_become_lists_get_a_row_major_evaluation_copy(monkeypatch):
+    """lk_rewarp_sectors turns implicit rectangles into explicit lists in the reference's order (x outer / y inner,
+    manager_class.cpp:1607-1611); the lane groups would then walk columns.  The move writes a second copy row by row:
+    the same samples at every level, and the next solve differs from the list-order walk by summation order only."""
+    frames = ca.speckle.speckle_sequence(320, 288, 3, velocity=(0.7, -0.4), dilation=6e-4, seed=9)
+
+    def run(flag):
+        monkeypatch.setenv("LK_EVAL_LISTS", flag)
+        e = ca.HipCorrelationEngine(py_stop=2)
+        e.set_undeformed_image(frames[0])
+        e.set_deformed_image(frames[1])
+        e.set_rect_grid(30.0, 30.0, 289.0, 257.0, 5, 4)
+        e.commit_sectors()
+        g = np.zeros(6, np.float32)
+        e.correlate_all(g)
+        e.rewarp_sectors()
+        e.makeUndPyramidFromDef()
+        e.set_deformed_image(frames[2])
+        lists = [[(e.level_xy(l, k), e.level_xy(l, k, evaluation_copy=True)) for l in range(3)] for k in range(e.n_sectors)] if flag == "1" else None
+        r = e.correlate_all(g)
+        e.close()
+        return r, lists
+
+    r1, lists = run("1")
+    r0, _ = run("0")
+    for k, per_level in enumerate(lists):
+        for l, (canon, ev) in enumerate(per_level):
+            assert len(canon) == len(ev) and len(canon) > 0, (k, l)
+            assert np.array_equal(canon[np.lexsort((canon[:, 0], canon[:, 1]))], ev[np.lexsort((ev[:, 0], ev[:, 1]))]), (k, l)
+            assert not np.array_equal(canon, ev), (k, l)
+    # level 0 of the copy: rows of the rectangle, x fastest (the move is smooth: y still grows row by row)
+    ev0 = lists[0][0][1]
+    w = int(np.argmax(np.diff(ev0[:, 0]) < 0)) + 1          # the first row's length
+    assert w > 8 and np.all(np.diff(ev0[:w, 0]) > 0) and abs(ev0[w, 1] - ev0[0, 1] - 1.0) < 0.1
+    assert np.array_equal(r1["error_code"], r0["error_code"])
+    ok = r1["error_code"] == 0
+    assert ok.sum() >= 15
+    assert np.abs(r1["p"][ok][:, :2] - r0["p"][ok][:, :2]).max() < 5e-4
+    assert (np.abs(r1["chi"][ok] - r0["chi"][ok]) / np.abs(r0["chi"][ok])).max() < 3e-3
 
 
 @pytest.mark.gpu
