@@ -2261,7 +2261,33 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
       // classes - and of the class below them while its sectors are no more than the CUs: a workgroup per sector then
       // shortens every sector's chain, beyond that the wavefronts' throughput wins)
       const int ref_group = c == 0 ? 16 : (c >= kTeamClass - 1 || (c == kTeamClass - 2 && n <= 256)) ? 512 : 64;
+      // number_of_threads = T > 1 on the big classes: a TEAM of T workgroups per sector, one thread chunk of the reference
+      // each (the launch falls back to one workgroup per sector when T x sectors are not all resident at once)
+      std::unique_lock<std::mutex> ref_team_turn;
+      hipEvent_t *ref_team_done = nullptr;
+      if (c >= kTeamClass - 1 && e->reference_order > 1 && e->reference_order <= kLkMaxTeam && (long long)n * e->reference_order <= 256 &&
+          !e->batch_invariant) {
+        const int T = e->reference_order;
+        HIPCHK(e->d_team_partials.ensure((size_t)n * 2 * (size_t)T * 32));
+        HIPCHK(e->d_team_arrivals.ensure(2 * (size_t)n));
+        a.team_w = T;
+        a.team_min_samples = 0;
+        a.team_partials = e->d_team_partials.p;
+        a.team_arrivals = e->d_team_arrivals.p;
+        a.team_fault = team_fault_hook();
+        if (e->cfg.device >= 0 && e->cfg.device < 64) { // (team launches of one device take turns, see below)
+          ref_team_turn = std::unique_lock<std::mutex>(g_team_mu);
+          ref_team_done = &g_team_done[e->cfg.device];
+          if (!*ref_team_done)
+            HIPCHK(hipEventCreateWithFlags(ref_team_done, hipEventDisableTiming));
+          else
+            HIPCHK(hipStreamWaitEvent(st, *ref_team_done, 0));
+        }
+      }
       HIPCHK(lk_launch_solve(a, e->cfg.fitting_model, e->cfg.interpolation, ref_group, st));
+      if (ref_team_done)
+        HIPCHK(hipEventRecord(*ref_team_done, st));
+      ref_team_turn = std::unique_lock<std::mutex>();
       if (st != e->stream) {
         HIPCHK(hipEventRecord(e->ev_join[c], st));
         HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join[c], 0));

@@ -370,6 +370,73 @@ struct TeamCtx {
   bool timed_out = false;
 };
 
+// The all-to-all of a team (see TeamCtx): every workgroup publishes its totals (or, in reference-order mode, the sums of
+// its thread chunk), waits for the others and adds all of them up in rank order, starting from zero - every workgroup
+// of the team ends with the same bits.  Returns the team's error flag.
+template <class SumsT>
+__device__ __forceinline__ bool team_all_to_all(SumsT &S, bool any_bad, float *lds, TeamCtx *team) {
+  const int team_w = team->w, team_rank = team->rank;
+  ++team->step;
+  float *mine = team->partials + (((size_t)team->slot * 2 + (team->step & 1u)) * (size_t)team->stride) * 32;
+  __syncthreads(); // everybody has its totals out of lds
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < SumsT::N; ++i)
+      mine[(size_t)team_rank * 32 + i] = S.v[i];
+    mine[(size_t)team_rank * 32 + SumsT::N] = any_bad ? 1.f : 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(team->fault && team->rank == 1 && (int)team->step == team->fault)) // (test hook: a workgroup goes missing)
+      __hip_atomic_fetch_add(team->arrivals + team->slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t target = team->step * (uint32_t)team_w;
+    uint32_t *broken = team->arrivals + team->n_slots + team->slot;
+    bool ok = false;
+    // normally a few microseconds; ~1 s bound.  A workgroup that gives up marks the team
+    // broken for everybody (see the kernel: rank 0 then solves the sector on its own).
+    for (int spin = 0; spin < (1 << 20); ++spin) {
+      if (__hip_atomic_load(team->arrivals + team->slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) {
+        ok = true;
+        break;
+      }
+      if ((spin & 255) == 255 && __hip_atomic_load(broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+        break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (!ok)
+      __hip_atomic_store(broken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      ok = __hip_atomic_load(broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds[0] = ok ? 0.f : 1.f;
+  }
+  __syncthreads();
+  const bool timeout = lds[0] != 0.f;
+  __syncthreads();
+  // The partials were written on other XCDs: a dependent chain of team_w remote loads per lane (the first
+  // version) cost 14-24 us per evaluation.  All 512 threads copy them into LDS first - every load in flight at
+  // once, one round trip - and then one lane per value adds them up in the same fixed order as before (config
+  // 3's blob, a team of 128: 0.75 -> 0.36 ms).
+  __shared__ float team_stage[kLkMaxTeam * 32];
+  for (int idx = (int)threadIdx.x; idx < team_w * 32; idx += 512)
+    team_stage[idx] = mine[idx];
+  __syncthreads();
+  if ((int)threadIdx.x <= SumsT::N) { // one lane per value: fixed summation order
+    float t = 0.f;
+    for (int w = 0; w < team_w; ++w)
+      t += team_stage[w * 32 + (int)threadIdx.x];
+    lds[threadIdx.x] = t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < SumsT::N; ++i)
+    S.v[i] = lds[i];
+  any_bad = lds[SumsT::N] != 0.f;
+  team->timed_out = team->timed_out || timeout;
+  return any_bad;
+}
+
 template <int MODEL, int INTERP, int GROUP, int THREADS>
 __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
                                          Sums<n_params(MODEL)> &S, float *lds, TeamCtx *team = nullptr,
@@ -681,66 +748,8 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
         eb += lds[w * STRIDE + SumsT::N];
       any_bad = eb != 0.f;
       if constexpr (GROUP == 512) {
-        if (team_w > 1) { // all-to-all of the workgroup totals inside the team
-          ++team->step;
-          float *mine = team->partials + (((size_t)team->slot * 2 + (team->step & 1u)) * (size_t)team->stride) * 32;
-          __syncthreads(); // everybody has its totals out of lds
-          if (threadIdx.x == 0) {
-#pragma unroll
-            for (int i = 0; i < SumsT::N; ++i)
-              mine[(size_t)team_rank * 32 + i] = S.v[i];
-            mine[(size_t)team_rank * 32 + SumsT::N] = any_bad ? 1.f : 0.f;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!(team->fault && team->rank == 1 && (int)team->step == team->fault)) // (test hook: a workgroup goes missing)
-              __hip_atomic_fetch_add(team->arrivals + team->slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t target = team->step * (uint32_t)team_w;
-            uint32_t *broken = team->arrivals + team->n_slots + team->slot;
-            bool ok = false;
-            // normally a few microseconds; ~1 s bound.  A workgroup that gives up marks the team
-            // broken for everybody (see the kernel: rank 0 then solves the sector on its own).
-            for (int spin = 0; spin < (1 << 20); ++spin) {
-              if (__hip_atomic_load(team->arrivals + team->slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) {
-                ok = true;
-                break;
-              }
-              if ((spin & 255) == 255 && __hip_atomic_load(broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
-                break;
-              __builtin_amdgcn_s_sleep(8);
-            }
-            if (!ok)
-              __hip_atomic_store(broken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else
-              ok = __hip_atomic_load(broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            lds[0] = ok ? 0.f : 1.f;
-          }
-          __syncthreads();
-          const bool timeout = lds[0] != 0.f;
-          __syncthreads();
-          // The partials were written on other XCDs: a dependent chain of team_w remote loads per lane (the first
-          // version) cost 14-24 us per evaluation.  All 512 threads copy them into LDS first - every load in flight at
-          // once, one round trip - and then one lane per value adds them up in the same fixed order as before (config
-          // 3's blob, a team of 128: 0.75 -> 0.36 ms).
-          __shared__ float team_stage[kLkMaxTeam * 32];
-          for (int idx = (int)threadIdx.x; idx < team_w * 32; idx += GROUP)
-            team_stage[idx] = mine[idx];
-          __syncthreads();
-          if ((int)threadIdx.x <= SumsT::N) { // one lane per value: fixed summation order
-            float t = 0.f;
-            for (int w = 0; w < team_w; ++w)
-              t += team_stage[w * 32 + (int)threadIdx.x];
-            lds[threadIdx.x] = t;
-          }
-          __syncthreads();
-#pragma unroll
-          for (int i = 0; i < SumsT::N; ++i)
-            S.v[i] = lds[i];
-          any_bad = lds[SumsT::N] != 0.f;
-          team->timed_out = team->timed_out || timeout;
-        }
+        if (team_w > 1) // all-to-all of the workgroup totals inside the team
+          any_bad = team_all_to_all(S, any_bad, lds, team);
       }
     }
     return any_bad;
@@ -928,9 +937,11 @@ constexpr int kWgOrdSamples = 7 * kWave;          // samples per trip: seven pro
 constexpr int kWgOrdStride = kWgOrdSamples + 4;   // (+4: the 128-bit reads of neighbouring owner lanes hit different banks)
 template <int N> constexpr int wg_ord_floats() { return 2 * N * kWgOrdStride; }
 
+// first, count: the samples [first, first + count) of the list only (one thread chunk of the reference, solved by one
+// workgroup of a team: see the kernel) - CHUNKED is then false, the chunk is one chain.
 template <int MODEL, int INTERP, bool CHUNKED>
 __device__ __forceinline__ bool evaluate_ordered_wg(const LevelCtx &c, const float (&p)[6], Sums<n_params(MODEL)> &S,
-                                                    float *ord, int threads) {
+                                                    float *ord, int threads, int first, int count) {
   constexpr int P = n_params(MODEL);
   using SumsT = Sums<P>;
   constexpr int N = SumsT::N, STR = kWgOrdStride;
@@ -940,23 +951,23 @@ __device__ __forceinline__ bool evaluate_ordered_wg(const LevelCtx &c, const flo
   const int v = lane < N ? lane : 0; // (idle lanes of the adding wavefront shadow sum 0)
   float acc = 0.f, tot = 0.f;
   const int T = CHUNKED ? (threads < 1 ? 1 : threads) : 1;
-  const int cq = c.n / T, cr = c.n - cq * T; // thread chunks of the reference: chunk t has n/T + (t < n%T) samples
-  int t_idx = 0, next_b = cq + (cr > 0 ? 1 : 0);
+  const int cq = count / T, cr = count - cq * T; // thread chunks of the reference: chunk t has n/T + (t < n%T) samples
+  int t_idx = 0, next_b = cq + (cr > 0 ? 1 : 0); // (positions relative to `first`)
   bool bad = false;
   const int umaxr = c.urows - 1, umaxc = c.ucols - 1;
   const int rh = c.rw > 0 ? c.n / c.rw : 1; // height of the implicit rectangle
   const float inv_rh = 1.f / (float)rh;
-  const int n_trips = (c.n + kWgOrdSamples - 1) / kWgOrdSamples;
+  const int n_trips = (count + kWgOrdSamples - 1) / kWgOrdSamples;
   __syncthreads(); // (the previous evaluation's readers of the tiles are done)
   for (int trip = 0; trip <= n_trips; ++trip) {
     if (!consumer && trip < n_trips) { // products of this trip's samples -> tile[trip & 1]
       float *tile = ord + (trip & 1) * (N * STR);
-      const int slot = (wave - 1) * kWave + lane, k = trip * kWgOrdSamples + slot;
+      const int slot = (wave - 1) * kWave + lane, rel = trip * kWgOrdSamples + slot, k = first + rel;
       float t[N];
 #pragma unroll
       for (int i = 0; i < N; ++i)
         t[i] = 0.f;
-      if (k < c.n) {
+      if (rel < count) {
         f32x2 q;
         if (c.rw > 0) { // x outer, y inner: k -> (column, row) of the rectangle
           int col = (int)((float)k * inv_rh); // k / rh to within one unit below 2^23 samples, two below 2^25
@@ -2396,8 +2407,19 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
       err = a.reference_order > 1 ? evaluate_ordered_flat<MODEL, INTERP, true>(ce, p, S, ord_lds, ord_ctx, a.reference_order)
                                   : evaluate_ordered_flat<MODEL, INTERP, false>(ce, p, S, ord_lds, ord_ctx, 1);
     } else if constexpr (ORD_WG) {
-      err = a.reference_order > 1 ? evaluate_ordered_wg<MODEL, INTERP, true>(ce, p, S, ord_lds, a.reference_order)
-                                  : evaluate_ordered_wg<MODEL, INTERP, false>(ce, p, S, ord_lds, 1);
+      if (team.w > 1) {
+        // A team in reference-order mode: its T = number_of_threads workgroups each solve ONE thread chunk of the
+        // reference (chunk t: n/T + (t < n%T) samples, correlation_class.cpp:169-186) as one ordered chain, and the
+        // all-to-all joins the chunk sums in thread order into zeroed totals (:253-275) - the reference's own
+        // parallelism, 20 chains side by side by default.  (A broken team: rank 0 alone walks all chunks, below.)
+        const int T = team.w, cq = ce.n / T, cr = ce.n - cq * T;
+        const int first = team.rank * cq + (team.rank < cr ? team.rank : cr), count = cq + (team.rank < cr ? 1 : 0);
+        err = evaluate_ordered_wg<MODEL, INTERP, false>(ce, p, S, ord_lds, 1, first, count);
+        err = team_all_to_all(S, err, lds, &team);
+      } else {
+        err = a.reference_order > 1 ? evaluate_ordered_wg<MODEL, INTERP, true>(ce, p, S, ord_lds, a.reference_order, 0, ce.n)
+                                    : evaluate_ordered_wg<MODEL, INTERP, false>(ce, p, S, ord_lds, 1, 0, ce.n);
+      }
     } else if constexpr (ORD) {
       err = a.reference_order > 1 ? evaluate_ordered<MODEL, INTERP, GROUP, true>(ce, p, S, ord_lds, a.reference_order)
                                   : evaluate_ordered<MODEL, INTERP, GROUP, false>(ce, p, S, ord_lds, 1);
@@ -3859,13 +3881,15 @@ static hipError_t launch_solve_gs(const LkSolveArgs &a, hipStream_t st) {
     if (a.slots_permille > 0) // (the rest of the slots belongs to the one-workgroup class's launch on a sibling stream)
       share = split_slots(share, a.slots_permille);
     b.team_w = a.team_w < share / a.n_sectors ? a.team_w : share / a.n_sectors;
+    if (REF && b.team_w != a.team_w) // (a reference-order team IS the reference's thread count: all of it or one workgroup)
+      b.team_w = 0;
     if (b.team_w > 1) {
       hipError_t te = hipMemsetAsync(a.team_arrivals, 0, 2 * (size_t)a.n_sectors * sizeof(uint32_t), st); // counters + broken flags
       if (te != hipSuccess)
         return te;
       b.persistent = 0;
       b.chunk = 0;
-      hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, GROUP, THREADS, SAFE>),
+      hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, GROUP, THREADS, SAFE, REF>),
                          dim3((unsigned)(a.n_sectors * b.team_w)), dim3(THREADS), 0, st, b);
       return hipGetLastError();
     }
