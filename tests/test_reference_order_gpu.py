@@ -358,3 +358,25 @@ def test_error_paths_and_ragged_sectors_are_bit_identical(oracle, speckle512, st
     assert_same_bytes(got0[0], o0.newton_raphson([0, 0], xy, center=(220.0, 220.0)), "max_iters = 0")
     assert got0["error_code"][0] == 3
     e0.close()
+
+
+@pytest.mark.parametrize("threads,py_stop", [(200, 4), (64, 3)])
+def test_reference_order_team_with_thread_chunks_of_a_sample_or_none(oracle, threads, py_stop):
+    """A big sector with number_of_threads = T > 1 is solved by a team of T workgroups, one thread chunk of the
+    reference each (correlation_class.cpp:169-186).  At the coarse levels the chunks shrink to one or two samples
+    (T = 200 on the 270 samples of level 4; ragged: the first n % T chunks are one longer): workgroups with nearly
+    empty chunks must still join the all-to-all in thread order.  Records bit-identical to the CPU engine."""
+    und, dfm = ca.speckle.speckle_pair(768, 768, p=(0.9, 0.4, 0.001, 0.0005, -0.0005, 0.0015), seed=21)
+    e, o = engine_and_oracle(oracle, (und, dfm), threads=threads, py_stop=py_stop)
+    t = 2 * np.pi * np.arange(24) / 24
+    rad = np.where(np.arange(24) % 2 == 0, 190.0, 130.0)
+    contour = np.stack([384 + rad * np.cos(t), 384 + rad * np.sin(t)], 1).astype(np.float32)
+    e.resetPolygon_blob(0, contour)
+    pts = oracle.blob_points(contour)
+    assert 65536 < len(pts) < 262144          # the one-workgroup class: a team in reference-order mode only
+    e.commit_sectors()
+    got = e.correlate_all(np.zeros(6, np.float32))
+    want = o.correlate_sectors([pts])
+    assert_same_bytes(got, want, f"blob, {threads} threads")
+    assert got["error_code"][0] == 0
+    e.close()
