@@ -380,3 +380,23 @@ def test_reference_order_team_with_thread_chunks_of_a_sample_or_none(oracle, thr
     assert_same_bytes(got, want, f"blob, {threads} threads")
     assert got["error_code"][0] == 0
     e.close()
+
+
+def test_broken_reference_order_team_falls_back_to_one_workgroup_with_the_same_bytes(oracle, monkeypatch):
+    """LK_TEAM_FAULT: rank 1 of the team never arrives at step 3 (a workgroup that is not resident - foreign kernels
+    holding the GPU).  The team gives up after its bounded wait, rank 0 starts the sector again as a lone workgroup and
+    walks all T thread chunks itself: the record is late, not different."""
+    monkeypatch.setenv("LK_TEAM_FAULT", "3")
+    und, dfm = ca.speckle.speckle_pair(768, 768, p=(0.9, 0.4, 0.001, 0.0005, -0.0005, 0.0015), seed=21)
+    e, o = engine_and_oracle(oracle, (und, dfm), threads=7)
+    t = 2 * np.pi * np.arange(24) / 24
+    rad = np.where(np.arange(24) % 2 == 0, 190.0, 130.0)
+    contour = np.stack([384 + rad * np.cos(t), 384 + rad * np.sin(t)], 1).astype(np.float32)
+    e.resetPolygon_blob(0, contour)
+    e.commit_sectors()
+    got = e.correlate_all(np.zeros(6, np.float32))
+    monkeypatch.delenv("LK_TEAM_FAULT")
+    want = o.correlate_sectors([oracle.blob_points(contour)])
+    assert_same_bytes(got, want, "blob, broken team")
+    assert got["error_code"][0] == 0
+    e.close()
