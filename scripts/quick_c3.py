@@ -16,7 +16,7 @@ e = ca.HipCorrelationEngine(fitting_model=ca.FM_UVUXUYVXVY)
 e.set_reference_order(int(os.environ.get("LK_REF_ORDER", 0)))
 e.set_undeformed_image(und)
 e.set_deformed_image(dfm)
-rs, as_, ri, ro = 8, 32, 600.0, 1800.0
+rs, as_, ri, ro = int(os.environ.get("LK_C3_RS", 8)), int(os.environ.get("LK_C3_AS", 32)), 600.0, 1800.0   # (LK_C3_RS x LK_C3_AS annular sectors)
 dr, da = np.float32((ro - ri) / rs), np.float32(2 * np.pi) / np.float32(as_)
 only = os.environ.get("LK_C3_ONLY", "")   # "annulus" / "blob": one of the two sector kinds alone
 n_ann = 0
