@@ -19,6 +19,7 @@
 #include <rocprofiler-sdk-roctx/roctx.h>
 
 #include <algorithm>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1323,7 +1324,7 @@ static int commit_impl(lk_engine *e, bool keep_state) {
   }
   if (device_levels) {
     const uint32_t total = (uint32_t)(cat[0].size() / 2);
-    HIPCHK(e->d_level_total.ensure(LK_MAX_LEVELS));
+    HIPCHK(e->d_level_total.ensure(2 * LK_MAX_LEVELS)); // (second half: scratch of the evaluation copy's passes)
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)e->d_level_total.p, (int)total, 1, e->stream));
     HIPCHK(e->d_pos.ensure((size_t)total + 1));
     HIPCHK(e->d_tiles.ensure((size_t)lk_decimate_tiles(total) + 2));
@@ -1336,6 +1337,77 @@ static int commit_impl(lk_engine *e, bool keep_state) {
                             hipMemcpyDeviceToHost, e->stream));
     }
     HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  // The row-major evaluation copy for lists that came from the host (LkLevelView::xy_eval; any permutation of a sector's
+  // samples is a valid walk for the unordered sums): a stable counting sort by image row of every sector whose list
+  // jumps back in y often - lists in the reference's x outer / y inner order do so once per column.  Left alone: lists
+  // that are row-major already, short sectors, LK_EVAL_LISTS=0.
+  {
+    const char *eval_flag = std::getenv("LK_EVAL_LISTS"); // test / tuning hook, read per commit
+    const bool eval_on = !(eval_flag && std::atoi(eval_flag) == 0);
+    std::vector<float> ecat[LK_MAX_LEVELS];
+    bool any_sorted = false;
+    std::vector<uint32_t> count;
+    std::vector<float> tmp;
+    auto sort_rows = [&](std::vector<float> &v, size_t b, size_t n) { // samples [b, b + n) of v: stable by (int)y
+      if (n < 64)
+        return false;
+      int ymin = INT_MAX, ymax = INT_MIN;
+      size_t back = 0;
+      for (size_t k = 0; k < n; ++k) {
+        const float y = v[2 * (b + k) + 1];
+        if (!(y > -1e6f && y < 1e6f))
+          return false; // (NaN / absurd coordinates: the solve reports them; nothing to gain here)
+        const int r = (int)y;
+        ymin = std::min(ymin, r), ymax = std::max(ymax, r);
+        back += k > 0 && y < v[2 * (b + k) - 1];
+      }
+      if (back < 8 || back * 2048 < n) // (row-major already, or nearly: a column-major list jumps back once per column)
+        return false;
+      count.assign((size_t)(ymax - ymin) + 2, 0u);
+      for (size_t k = 0; k < n; ++k)
+        ++count[(size_t)((int)v[2 * (b + k) + 1] - ymin) + 1];
+      for (size_t r = 1; r < count.size(); ++r)
+        count[r] += count[r - 1];
+      tmp.resize(2 * n);
+      for (size_t k = 0; k < n; ++k) {
+        const uint32_t at = count[(size_t)((int)v[2 * (b + k) + 1] - ymin)]++;
+        tmp[2 * at] = v[2 * (b + k)], tmp[2 * at + 1] = v[2 * (b + k) + 1];
+      }
+      std::memcpy(&v[2 * b], tmp.data(), 2 * n * sizeof(float));
+      return true;
+    };
+    if (eval_on && !cat[0].empty()) {
+      for (int l : levels) {
+        if (device_levels && l > 0)
+          break;
+        ecat[l] = cat[l];
+        for (int s = 0; s < S; ++s)
+          if (e->h_rect[l][(size_t)s].z == 0) {
+            const size_t b = e->h_off[l][(size_t)s], n = e->h_off[l][(size_t)s + 1] - b;
+            any_sorted = sort_rows(ecat[l], b, n) || any_sorted;
+          }
+      }
+    }
+    if (any_sorted) {
+      for (int l : levels) {
+        const bool on_device = device_levels && l > 0;
+        HIPCHK(e->d_xy_eval[l].ensure((on_device ? cat[0].size() : cat[l].size()) / 2 + 1));
+        if (!on_device && !ecat[l].empty())
+          HIPCHK(hipMemcpy(e->d_xy_eval[l].p, ecat[l].data(), ecat[l].size() * sizeof(float), hipMemcpyHostToDevice));
+      }
+      if (device_levels) { // the same decimation of the copy: the same sets, the offsets already computed
+        const uint32_t total = (uint32_t)(cat[0].size() / 2);
+        HIPCHK(e->d_off_eval.ensure((size_t)S + 1));
+        for (size_t li = 1; li < levels.size(); ++li) {
+          const int l = levels[li], pl = levels[li - 1];
+          HIPCHK(lk_launch_decimate(e->d_xy_eval[pl].p, e->d_off[pl].p, e->d_level_total.p + pl, total, l - pl, S, e->d_pos.p,
+                                    e->d_tiles.p, e->d_xy_eval[l].p, e->d_off_eval.p, e->d_level_total.p + LK_MAX_LEVELS + l, e->stream));
+        }
+        HIPCHK(hipStreamSynchronize(e->stream));
+      }
+      e->eval_lists = true;
+    }
   }
   e->lists_on_device = false;
   } // !device_roi

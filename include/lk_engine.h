@@ -245,7 +245,8 @@ int lk_get_und_xy(lk_engine *e, int sector, float *xy, int cap, int *count);
 /* Diagnostics: the explicit sample list of a sector at a pyramid level as the device holds it (pyramid_class.cpp:289-323:
  * the decimated lists).  which = 0: the reference's order - what the centres, the starved levels and the reference-order
  * mode walk.  which = 1: the row-major evaluation copy the lane groups of the default mode walk (annular sectors rasterised
- * by the device masks; the same samples, y outer / x inner, so that neighbouring lanes read neighbouring pixels) -
+ * by the device masks, lists from the host in the reference's x outer / y inner order, moved lists; the same samples row by
+ * row, so that neighbouring lanes read neighbouring pixels) -
  * LK_ERROR_BAD_DOMAIN when the domain has none.  Implicit rectangles have no list (count 0). */
 int lk_get_level_xy(lk_engine *e, int level, int which, int sector, float *xy, int cap, int *count);
 /* CudaClass::getDefXY0ToCPU / CorrelationClass::getDefXY0 (cuda_class.cu:611-613,

@@ -1907,3 +1907,48 @@ def test_sectors_appended_one_by_one_equal_the_full_commit(speckle512):
     assert c[keep].tobytes() == a[keep].tobytes() and c[2]["und_cx"] == 213.0
     e.close()
     ref.close()
+
+
+@pytest.mark.gpu
+def test_lists_from_the_host_get_a_row_major_evaluation_copy_too(oracle, monkeypatch):
+    """lk_set_sector_points with lists in the reference's order (x outer / y inner): the commit sorts a copy of every
+    such list by image row (stable counting sort) for the lane groups of the default mode, at every level - short lists
+    on the host, long ones through the device decimation.  Same samples; records differ from the list-order walk by
+    summation order only; a list that is row-major already is left alone."""
+    und, dfm = ca.speckle.speckle_pair(768, 768, p=(0.9, 0.4, 0.001, 0.0005, -0.0005, 0.0015), seed=21)
+    ann = [oracle.annular_points(np.float32(150.0 + 60 * i), np.float32(60.0), np.float32(j) * np.float32(np.pi / 2), np.float32(np.pi / 2),
+                                 384.0, 380.0, 4) for i in range(3) for j in range(4)]
+    xs, ys = np.meshgrid(np.arange(40, 140), np.arange(50, 120), indexing="xy")          # a rectangle given row by row
+    rows_first = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.float32)
+
+    def run(flag, n_lists):
+        monkeypatch.setenv("LK_EVAL_LISTS", flag)
+        e = ca.HipCorrelationEngine(py_stop=2)
+        e.set_undeformed_image(und)
+        e.set_deformed_image(dfm)
+        for s, pts in enumerate(ann[:n_lists]):
+            e.set_sector_points(s, pts)
+        e.set_sector_points(n_lists, rows_first)
+        e.commit_sectors()
+        lists = None
+        if flag == "1":
+            lists = [[(e.level_xy(l, k), e.level_xy(l, k, evaluation_copy=True)) for l in range(3)] for k in range(e.n_sectors)]
+        r = e.correlate_all(np.zeros(6, np.float32))
+        e.close()
+        return r, lists
+
+    for n_lists in (2, 12):      # 2: below 32 768 samples in all - levels decimated on the host; 12: on the device
+        r1, lists = run("1", n_lists)
+        r0, _ = run("0", n_lists)
+        for k, per_level in enumerate(lists):
+            for l, (canon, ev) in enumerate(per_level):
+                assert len(canon) == len(ev) and len(canon) > 0, (k, l)
+                if k == n_lists:
+                    assert np.array_equal(canon, ev), l                       # row-major already: untouched
+                    continue
+                order = np.argsort(canon[:, 1], kind="stable")
+                assert np.array_equal(canon[order], ev), (k, l)               # stable by row
+                assert not np.array_equal(canon, ev), (k, l)
+        assert np.array_equal(r1["error_code"], r0["error_code"]) and (r1["error_code"] == 0).all()
+        assert np.abs(r1["p"][:, :2] - r0["p"][:, :2]).max() < 5e-4
+        assert (np.abs(r1["chi"] - r0["chi"]) / np.abs(r0["chi"])).max() < 3e-3
