@@ -24,3 +24,15 @@ timeout -k 10 250 rocprofv3 --kernel-trace -d "$out/c3" -o t -- python3 scripts/
 python3 scripts/c4_chain_timeline.py "$out/c3/t_results.db" 6 >> "$f" 2>&1
 rm -rf "$out/c3"
 cat "$f"
+# counters of the 512-thread instance on the annulus, lists in the reference's order against the row-major copy
+# (separate --pmc passes, no tracing): L2 requests (TCC_HIT + TCC_MISS), VALU instructions, wait and wave cycles
+for ev in 0 1; do
+  i=0
+  for set in "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "FETCH_SIZE"; do
+    i=$((i + 1))
+    LK_C3_ONLY=annulus LK_EVAL_LISTS=$ev timeout -k 10 150 rocprofv3 --pmc $set --output-format csv -d "$out/pmc$i" -o pmc -- python3 scripts/quick_c3.py 2 > "$out/c3pmc_${ev}_$i.log" 2>&1 || echo "c3 pass $ev/$i failed" >> "$out/progress.log"
+  done
+  python3 scripts/summarize_pmc.py "$out" "$tag config 3 annulus, LK_EVAL_LISTS=$ev" 2>/dev/null | grep -E "units|passes|lk_solve_kernel<3, 2, 512" > "$out/${tag}_c3_pmc_eval$ev.txt"
+  rm -rf "$out"/pmc*/
+done
+cat "$out/${tag}_c3_pmc_eval0.txt" "$out/${tag}_c3_pmc_eval1.txt"
