@@ -99,7 +99,9 @@ def other_configs(ca):
     from correlation_amd.workload import C4, C4B, C5
     out = {}
 
-    def timed(e, n=3):
+    valu_per_solve = profile_constants().get("valu_insts_per_solve", {})   # (profile constants: profiles/*_traffic.json)
+
+    def timed(e, n=3, config=None):
         g = np.zeros(6, np.float32)
         r = e.correlate_all(g)
         ms = []
@@ -108,10 +110,13 @@ def other_configs(ca):
             ms.append(e.stats()["solve_ms"])
         st = e.stats()
         ms = float(np.median(ms))
-        return r, {"solve_ms": ms, "sectors": int(len(r)), "point_iterations_per_s": st["point_iterations"] / (ms * 1e-3),
-                   "algorithmic_GBps": st["algorithmic_bytes"] / (ms * 1e-3) / 1e9,
-                   "evaluations_per_sector": st["evaluations"] / st["sectors"],
-                   "error_free_fraction": float((r["error_code"] == 0).mean())}
+        m = {"solve_ms": ms, "sectors": int(len(r)), "point_iterations_per_s": st["point_iterations"] / (ms * 1e-3),
+             "algorithmic_GBps": st["algorithmic_bytes"] / (ms * 1e-3) / 1e9,
+             "evaluations_per_sector": st["evaluations"] / st["sectors"],
+             "error_free_fraction": float((r["error_code"] == 0).mean())}
+        if config in valu_per_solve:   # share of the chip's VALU issue slots over the whole launch chain of the solve
+            m["valu_issue_frac"] = valu_issue_frac(valu_per_solve[config], ms)
+        return r, m
 
     def parity_block(wl, und, dfm, r):
         """default mode against the CPU oracle (1 thread order) on every sector of a starved config: error codes,
@@ -148,7 +153,7 @@ def other_configs(ca):
         e.set_deformed_image(dfm)
         e.set_rect_grid(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, wl.hs, wl.vs)
         e.commit_sectors()
-        r, m = timed(e)
+        r, m = timed(e, config=wl.name.split(":")[0])
         c = wl.size / 2.0
         ok = r["error_code"] == 0
         u_true = truth[0] + truth[2] * (r["und_cx"] - c) + truth[3] * (r["und_cy"] - c)
@@ -215,7 +220,7 @@ def other_configs(ca):
         rad = np.where(np.arange(64) % 2 == 0, 1500.0, 900.0)
         e.resetPolygon_blob(s, np.stack([2048 + rad * np.cos(t), 2048 + rad * np.sin(t)], 1).astype(np.float32))
         e.commit_sectors()
-        r, m = timed(e)
+        r, m = timed(e, config="C3")
         u_true = truth[0] + truth[2] * (r["und_cx"] - 2048) + truth[3] * (r["und_cy"] - 2048)
         m["max_abs_u_minus_truth"] = float(np.nanmax(np.abs(r["p"][:, 0] - u_true)))
         m["nan_records"] = int(np.isnan(r["p"]).any(1).sum())

@@ -78,5 +78,21 @@ fi
 LK_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout -k 10 400 python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-other-configs > "$out/${tag}_bench_dist_rehearsal.json" 2> "$out/bench_dist.err"
 rm -rf "$out/c4" "$out"/pmc*/ "$out/trace" "$out"/*.npz
 scripts/profile_c3.sh "$tag" > /dev/null 2>&1   # config 3: <tag>_c3_steps.txt
+# VALU instructions of one solve of configs 3, 4 and 5 (all launches of the chain) -> <tag>_traffic.json (bench.py: other_configs.*.valu_issue_frac)
+declare -A vps
+for wl in C4 C5; do   # (quick_solve.py WL 3: 1 + 3 solves)
+  timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d "$out/vps_$wl" -o pmc -- python3 scripts/quick_solve.py $wl 3 > "$out/vps_$wl.log" 2>&1
+  vps[$wl]=$(python3 scripts/valu_per_solve.py "$out/vps_$wl" 4 2>> "$out/vps_kernels.txt")
+done
+timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d "$out/vps_C3" -o pmc -- python3 scripts/quick_c3.py 3 > "$out/vps_C3.log" 2>&1   # (1 + 3 solves)
+vps[C3]=$(python3 scripts/valu_per_solve.py "$out/vps_C3" 4 2>> "$out/vps_kernels.txt")
+python3 - "$out/${tag}_traffic.json" "${vps[C3]}" "${vps[C4]}" "${vps[C5]}" <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+d["valu_insts_per_solve"] = {"C3": float(sys.argv[2]), "C4": float(sys.argv[3]), "C5": float(sys.argv[4]),
+                             "source": "rocprofv3 --pmc SQ_INSTS_VALU over scripts/quick_c3.py / quick_solve.py C4 / C5: all lk_solve_kernel launches of one solve"}
+json.dump(d, open(sys.argv[1], "w"), indent=1)
+PY
+rm -rf "$out"/vps_C*/
 tail -1 "$out/${tag}_bench.json" | cut -c1-400
 cat "$out/${tag}_pmc_summary.txt"
