@@ -185,7 +185,7 @@ static const int kNumClasses = 6;
 static const int kTeamClass = 5;
 static const int kGroupOfClass[kNumClasses] = {16, 32, 64, 256, 512, 512};
 static const int kTeamSamples = 32768; // level-0 samples per workgroup of a team (64 per lane)
-static const int kMaxTeam = 128;
+static const int kMaxTeam = kLkMaxTeam; // (256: config 3's blob alone 0.405 -> 0.372 ms against 128; the launch clamps a team to what is resident)
 static const int kTeamMinSamples = 4096; // a team workgroup is worth its all-to-all from 8 samples per lane on
 static const int kFewBigSectors = 128;   // at most this many 8-wavefront sectors: give them teams
 static int size_class(int n0) {
