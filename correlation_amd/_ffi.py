@@ -94,6 +94,14 @@ SYMBOLS = {
     "lk_get_results_device": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
     "lk_correlate_all_async": (C.c_int, [_P]),
     "lk_wait_results": (C.c_int, [_P, _P]),
+    "lk_sequence_reserve": (C.c_int, [_P, C.c_int]),
+    "lk_sequence_set_frame": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
+    "lk_sequence_set_frame_device": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
+    "lk_correlate_sequence_async": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "lk_wait_sequence": (C.c_int, [_P, _P]),
+    "lk_get_sequence_results_device": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "lk_sequence_is_pipelined": (C.c_int, [_P]),
+    "lk_get_sequence_guesses": (C.c_int, [_P, _F]),
     "lk_adjust_initial_guess": (C.c_int, [_P, C.c_int, C.c_int, _F, C.c_float, C.c_float]),
     "lk_get_guesses": (C.c_int, [_P, _F]),
     "lk_evaluate": (C.c_int, [_P, C.c_int, C.c_int, _F, _F, _F, _F, _I]),

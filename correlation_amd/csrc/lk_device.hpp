@@ -35,6 +35,19 @@ struct LkHandoff {
   uint32_t n_evals, n_sample_evals, n_point_iters;
 };
 
+// Frame-pipelined solve (lk_correlate_sequence*): the image pair of one frame of the window, level by level.
+// The sample lists, rectangles and dimensions are those of LkLevelView (an Eulerian sequence: the sectors stay,
+// only the images change from frame to frame).
+struct LkSeqFrame {
+  const uint8_t *und[LK_MAX_LEVELS];
+  const uint8_t *def[LK_MAX_LEVELS];
+};
+// What one frame of a sector hands to the next: its returned parameters as six 8-byte granules {tag = frame + 1, float
+// bits}, two slots per sector (frame parity) - one 128-byte line per sector.  A granule is written by ONE write-through
+// store and read by write-through-aware loads; the tag is the flag, so no fence and no ordering between the six is needed
+// (the consumer takes a value only when its tag is the frame it waits for).
+constexpr int kLkSeqChainWords = 16; // uint64 per sector: [2 slots][8] (6 used)
+
 constexpr int kLkMaxTeam = 256; // workgroups per team at most (the kernel stages a team's partial sums in LDS: 32 floats each)
 constexpr int kLkMidWords = 32; // Cold (23) + p (6) + phase
 
@@ -89,6 +102,21 @@ struct LkSolveArgs {
   int py_start, py_step, py_stop;
   float precision;
   int max_iters;
+  // Frame-pipelined solve of a sequence window (the SEQ instances): seq_frames > 0.  Tickets of the persistent queue
+  // are (frame, sector) pairs drawn FRAME-MAJOR (ticket t: frame t / n_sectors, sector order[t % n_sectors]); the group
+  // that draws (f, s) waits - without blocking the other sectors of its wavefront - until frame f - 1 of sector s has
+  // published its parameters, forms the guess of managerClass::adjust_initial_guess (manager_class.cpp:2677-2699) from
+  // them, solves, writes result[f * seq_stride + s] and publishes in turn.  Every wait targets a ticket that was drawn
+  // earlier, i.e. one a running or finished wavefront holds: the grid drains whatever is resident.
+  int seq_frames;
+  int seq_velocity;             // 1: guess = 2 p(f-1) - p(f-2) (Eulerian description, first image as the reference), 0: p(f-1)
+  int seq_stride;               // records per frame in `result` / `stats` / `seq_guess_out` (the engine's sector count)
+  const LkSeqFrame *seq_img;    // [seq_frames]
+  unsigned long long *seq_chain; // [S][kLkSeqChainWords] granules, zeroed before the launch
+  const float *seq_prev_p;      // [S][6] previous_resulting_parameters before the window (p(f-2) of the window's frame 1)
+  float *seq_prev_p_out;        // [S][6] ... and after it (written by the window's last frame; a buffer of its own)
+  float *seq_guess_out;         // optional [seq_frames][seq_stride][6]: the guesses the frames were solved from
+  uint32_t *seq_flags;          // [0]: a wait ran into its bound (the launch is void); [1]: a fast-flavour solve met a bad pivot
 };
 
 // ROI -> level-0 sample lists on the device (cudaPolygon's mask + compaction, cuda_polygon.cuh:180-292,

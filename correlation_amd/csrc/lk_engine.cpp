@@ -29,6 +29,7 @@
 #include <vector>
 
 hipError_t lk_launch_solve(const LkSolveArgs &a, int model, int interp, int group, hipStream_t st);
+hipError_t lk_launch_solve_seq(const LkSolveArgs &a, int model, int interp, int group, int flavour, hipStream_t st);
 hipError_t lk_launch_eval(const LkEvalArgs &a, int model, int interp, int group, hipStream_t st);
 hipError_t lk_launch_solve_only(int n, const float *d_in, float *d_out, hipStream_t st);
 hipError_t lk_launch_sample(int interp, const uint8_t *def, int rows, int cols, const float2 *pts, int n,
@@ -274,6 +275,31 @@ struct lk_engine {
   DevBuf<uint32_t> d_team_arrivals;
   DevBuf<float> d_scratch; // 64 floats for the stand-alone entry points
   DevBuf<float2> d_warp;
+  // Frame-pipelined windows (lk_correlate_sequence_async): a ring of resident deformed-frame pyramids, filled on the
+  // next-frame stream, and the buffers of one window - records and counters per frame, the per-sector granule chain that
+  // hands a sector's parameters from frame to frame, the per-frame image table, two flag words.
+  std::vector<DevImage> ring;
+  std::vector<hipEvent_t> ring_ready;   // per slot: its pyramid is built (recorded on nxt_stream)
+  std::vector<char> ring_fresh;         // per slot: ring_ready has to be waited for by the next window that reads it
+  std::vector<unsigned> ring_window;    // per slot: the last window that read it (+ 1; 0: none)
+  hipEvent_t seq_done[4] = {nullptr, nullptr, nullptr, nullptr}; // recorded behind window w on the engine's stream: [w % 4]
+  unsigned seq_windows = 0;             // windows launched so far
+  DevBuf<lk_result> d_seq_result;       // [frames][S]
+  DevBuf<uint32_t> d_seq_stats;         // [frames][S][4]
+  DevBuf<float> d_seq_guess;            // [frames][S][6] (LK_SEQ_CHECK / tests)
+  DevBuf<unsigned long long> d_seq_chain;
+  DevBuf<LkSeqFrame> d_seq_img;
+  DevBuf<uint32_t> d_seq_flags;         // [4]: wait bound hit, bad pivot in the fast flavour
+  DevBuf<float> d_prev_p_alt;           // previous_resulting_parameters as the window's last frame leaves them
+  struct SeqWindow {
+    int und_slot = -1, first_slot = 0, n_frames = 0, reference_previous = 0, velocity = 0, want_host = 0, want_guesses = 0;
+    bool pipelined = false, outstanding = false;
+  } seq;
+  uint32_t *h_seq_flags = nullptr;      // pinned [4]
+  lk_result *h_seq_results = nullptr;   // pinned [frames][S]
+  size_t h_seq_results_n = 0;
+  hipEvent_t ev_seq = nullptr;
+  int stats_frames = 1;                 // frames the counters of the last solve cover (a window: its frames)
   lk_result *h_results = nullptr; // pinned: where lk_correlate_all_async leaves the records
   size_t h_results_n = 0;
   hipEvent_t ev_results = nullptr;
@@ -388,6 +414,29 @@ void lk_destroy(lk_engine *e) {
   e->d_warp.release();
   e->d_team_partials.release();
   e->d_team_arrivals.release();
+  for (auto &im : e->ring)
+    for (auto &p : im.lvl)
+      if (p)
+        (void)hipFree(p);
+  for (hipEvent_t ev : e->ring_ready)
+    if (ev)
+      (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : e->seq_done)
+    if (ev)
+      (void)hipEventDestroy(ev);
+  if (e->ev_seq)
+    (void)hipEventDestroy(e->ev_seq);
+  e->d_seq_result.release();
+  e->d_seq_stats.release();
+  e->d_seq_guess.release();
+  e->d_seq_chain.release();
+  e->d_seq_img.release();
+  e->d_seq_flags.release();
+  e->d_prev_p_alt.release();
+  if (e->h_seq_flags)
+    (void)hipHostFree(e->h_seq_flags);
+  if (e->h_seq_results)
+    (void)hipHostFree(e->h_seq_results);
   for (hipStream_t cs : e->class_stream)
     if (cs)
       (void)hipStreamDestroy(cs);
@@ -496,30 +545,15 @@ static int prepare_slot(lk_engine *e, DevImage &im, int rows, int cols, hipStrea
   return LK_ERROR_NONE;
 }
 
-static int set_image_common(lk_engine *e, int slot, const void *src, bool src_on_device, int rows,
-                            int cols, int step) {
-  Range range_("lk:upload+pyramid");
-  if (!e)
-    return LK_ERROR_BAD_DOMAIN;
-  if (slot < 0 || slot > 2 || !src || rows < 1 || cols < 1 || step < cols)
-    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_image: bad arguments");
-  HIPCHK(hipSetDevice(e->cfg.device));
-  // the next-frame slot is filled on its own stream so it can overlap a running solve
-  // (manager_class.cpp:1438-1447 / nxtStream in cuda_pyramid.cu:504,557)
-  std::unique_lock<std::mutex> lock(e->nxt_mu, std::defer_lock);
-  hipStream_t st = e->stream;
-  if (slot == LK_IMG_NXT) {
-    lock.lock();
-    st = e->nxt_stream;
-  }
-  DevImage &im = e->img[slot];
+// upload (or device copy) of one frame into `im` + its pyramid levels, on stream `st`
+static int fill_image(lk_engine *e, DevImage &im, const void *src, bool src_on_device, int rows, int cols, int step,
+                      hipStream_t st, bool timed) {
   {
     int rc = prepare_slot(e, im, rows, cols, st);
     if (rc)
       return rc;
   }
   int r = rows, c = cols;
-  const bool timed = slot != LK_IMG_NXT && e->timing;
   // two or more pyramid levels on a device-resident frame: upload copy + levels 1, 2 in ONE
   // launch (lk_pyramid2_kernel); host frames are copied first and the kernel runs in place
   const bool fused = e->cfg.py_stop >= 2 && rows >= 4 && cols >= 4;
@@ -552,15 +586,38 @@ static int set_image_common(lk_engine *e, int slot, const void *src, bool src_on
   im.rows = rows;
   im.cols = cols;
   im.valid = true;
+  return LK_ERROR_NONE;
+}
+
+static int set_image_common(lk_engine *e, int slot, const void *src, bool src_on_device, int rows,
+                            int cols, int step) {
+  Range range_("lk:upload+pyramid");
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (slot < 0 || slot > 2 || !src || rows < 1 || cols < 1 || step < cols)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_set_image: bad arguments");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  // the next-frame slot is filled on its own stream so it can overlap a running solve
+  // (manager_class.cpp:1438-1447 / nxtStream in cuda_pyramid.cu:504,557)
+  std::unique_lock<std::mutex> lock(e->nxt_mu, std::defer_lock);
+  hipStream_t st = e->stream;
+  if (slot == LK_IMG_NXT) {
+    lock.lock();
+    st = e->nxt_stream;
+  }
+  DevImage &im = e->img[slot];
+  {
+    int rc = fill_image(e, im, src, src_on_device, rows, cols, step, st, slot != LK_IMG_NXT && e->timing);
+    if (rc)
+      return rc;
+  }
   if (slot == LK_IMG_NXT) {
     HIPCHK(hipEventRecord(e->nxt_done, st));
     e->nxt_pending = true;
   } else {
     e->lv_dirty = true;
   }
-  if (!src_on_device && slot != LK_IMG_NXT) // pageable host memory: the copy must have left it
-    HIPCHK(hipStreamSynchronize(st));
-  if (!src_on_device && slot == LK_IMG_NXT)
+  if (!src_on_device) // pageable host memory: the copy must have left it
     HIPCHK(hipStreamSynchronize(st));
   return LK_ERROR_NONE;
 }
@@ -2159,6 +2216,13 @@ static int refresh_level_views(lk_engine *e) {
   return LK_ERROR_NONE;
 }
 
+// Which flavour of the lane-group kernels a solve uses.  The fast flavour hands a sector whose damped system met a bad pivot
+// to a second, SAFE pass; the SAFE flavour runs the reference's QR for such a system inside the kernel.  Batch-invariant mode
+// takes the SAFE flavour throughout: a sector's arithmetic then is ONE kernel's from its guess to its record, whatever else
+// is in the batch and whoever solves it - in particular the frame-pipelined instances (which have no second pass to hand a
+// sector to) produce the very same bytes as the one-pair launches.
+static bool safe_flavour(const lk_engine *e) { return e->force_safe || e->batch_invariant; }
+
 static LkSolveArgs base_args(lk_engine *e, const float *d_guess, lk_result *d_result) {
   LkSolveArgs a{};
   a.lv = e->d_lv.p;
@@ -2301,7 +2365,7 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
     a.order = e->d_order.p + e->class_begin[c];
     a.n_sectors = n;
     a.queue = e->d_queue.p + 8 * c;
-    a.safe = e->force_safe ? 1 : 0;
+    a.safe = safe_flavour(e) ? 1 : 0;
     if (e->reference_order > 0) {
       // Reference-order mode: ONE launch per class, every level with the ordered sums and the
       // restated QR - a 16-lane row per small sector (four sectors share a wavefront's QR),
@@ -2415,6 +2479,7 @@ static int launch_all(lk_engine *e, const float *d_guess, lk_result *d_result) {
     e->solve_timed = true;
   }
   e->stats_valid = false;
+  e->stats_frames = 1;
   return LK_ERROR_NONE;
 }
 
@@ -2538,7 +2603,7 @@ int lk_correlate(lk_engine *e, int sector, float *guess_inout, lk_result *out) {
   const int group = kGroupOfClass[e->h_class[(size_t)sector]];
   a.n_sectors = 1;
   a.queue = e->d_queue.p;
-  a.safe = e->force_safe ? 1 : 0;
+  a.safe = safe_flavour(e) ? 1 : 0;
   if (e->reference_order > 0) { // (see launch_all)
     a.safe = 1;
     a.solo = 0;
@@ -2554,6 +2619,7 @@ int lk_correlate(lk_engine *e, int sector, float *guess_inout, lk_result *out) {
       e->solve_timed = true;
     }
     e->stats_valid = false;
+    e->stats_frames = 1;
     HIPCHK(hipMemcpyAsync(out, e->d_result.p + sector, sizeof(lk_result), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     for (int i = 0; i < e->P; ++i)
@@ -2597,6 +2663,7 @@ int lk_correlate(lk_engine *e, int sector, float *guess_inout, lk_result *out) {
     e->solve_timed = true;
   }
   e->stats_valid = false;
+  e->stats_frames = 1;
   HIPCHK(hipMemcpyAsync(out, e->d_result.p + sector, sizeof(lk_result), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   for (int i = 0; i < e->P; ++i)
@@ -2628,6 +2695,399 @@ int lk_get_guesses(lk_engine *e, float *guesses) {
   HIPCHK(hipSetDevice(e->cfg.device));
   HIPCHK(hipMemcpyAsync(guesses, e->d_guess.p, 6 * (size_t)e->S * sizeof(float), hipMemcpyDeviceToHost,
                         e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return LK_ERROR_NONE;
+}
+
+// ------------------------------------------------------------------------------------
+// Frame-pipelined windows of a sequence (perform_multiframe_correlation's frame loop,
+// manager_class.cpp:1380-1496, with the Eulerian description: the sectors stay, the deformed
+// image changes, and the guess of frame f + 1 of a sector is a function of that sector's own
+// earlier results, :2677-2699).  K deformed frames are resident at once (the ring); ONE launch
+// per size class solves all of them, every sector advancing from frame to frame on its own
+// (the SEQ instances of lk_solve_kernel), instead of one launch - and one straggler tail - per pair.
+// ------------------------------------------------------------------------------------
+int lk_sequence_reserve(lk_engine *e, int n_slots) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (n_slots < 1 || n_slots > 4096)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_sequence_reserve: n_slots must be in 1..4096");
+  if (e->seq.outstanding)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_sequence_reserve: a window is outstanding (lk_wait_sequence)");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  std::lock_guard<std::mutex> lock(e->nxt_mu);
+  if ((int)e->ring.size() < n_slots) {
+    const size_t old = e->ring.size();
+    e->ring.resize((size_t)n_slots);
+    e->ring_ready.resize((size_t)n_slots, nullptr);
+    e->ring_fresh.resize((size_t)n_slots, 0);
+    e->ring_window.resize((size_t)n_slots, 0u);
+    for (size_t i = old; i < (size_t)n_slots; ++i)
+      HIPCHK(hipEventCreateWithFlags(&e->ring_ready[i], hipEventDisableTiming));
+  }
+  return LK_ERROR_NONE;
+}
+
+static int sequence_set_frame(lk_engine *e, int slot, const void *src, bool on_device, int rows, int cols, int step) {
+  Range range_("lk:upload+pyramid (ring)");
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!src || rows < 1 || cols < 1 || step < cols)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_sequence_set_frame: bad arguments");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  // like the next-frame slot: filled on the next-frame stream, so that the frames of window w + 1 arrive and get their
+  // pyramids while window w is being solved (manager_class.cpp:1438-1447)
+  std::unique_lock<std::mutex> lock(e->nxt_mu);
+  if (slot < 0 || slot >= (int)e->ring.size())
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_sequence_set_frame: unknown ring slot (lk_sequence_reserve)");
+  hipStream_t st = e->nxt_stream;
+  if (e->ring_window[(size_t)slot]) // a window read this slot: it must be through with it (stream order on the device)
+    HIPCHK(hipStreamWaitEvent(st, e->seq_done[(e->ring_window[(size_t)slot] - 1) % 4], 0));
+  int rc = fill_image(e, e->ring[(size_t)slot], src, on_device, rows, cols, step, st, false);
+  if (rc)
+    return rc;
+  HIPCHK(hipEventRecord(e->ring_ready[(size_t)slot], st));
+  e->ring_fresh[(size_t)slot] = 1;
+  lock.unlock();
+  if (!on_device) // pageable host memory: the copy must have left it
+    HIPCHK(hipStreamSynchronize(st));
+  return LK_ERROR_NONE;
+}
+
+int lk_sequence_set_frame(lk_engine *e, int slot, const uint8_t *host_pixels, int rows, int cols, int step) {
+  return sequence_set_frame(e, slot, host_pixels, false, rows, cols, step);
+}
+int lk_sequence_set_frame_device(lk_engine *e, int slot, const void *device_pixels, int rows, int cols, int step) {
+  return sequence_set_frame(e, slot, device_pixels, true, rows, cols, step);
+}
+
+// lane group and flavour of a class inside a window (-1: the class has no frame-pipelined instance)
+static int seq_group_of_class(const lk_engine *e, int c, int n) {
+  if (e->reference_order > 0) { // (launch_all's rule)
+    const int g = c == 0 ? 16 : (c >= kTeamClass - 1 || (c == kTeamClass - 2 && n <= 256)) ? 512 : 64;
+    return g == 512 ? -1 : g;
+  }
+  const int g = kGroupOfClass[c];
+  if (g > 64)
+    return -1;
+  if (e->class_starved[c] && g != 16) // (starved levels inside the window: the 16-lane rows' finisher arithmetic)
+    return -1;
+  return g;
+}
+
+static bool seq_pipelinable(const lk_engine *e) {
+  static const bool off = [] { const char *f = std::getenv("LK_SEQ_PIPELINE"); return f && std::atoi(f) == 0; }(); // comparison hook
+  if (off)
+    return false;
+  for (int c = 0; c < kNumClasses; ++c) {
+    const int n = e->class_begin[c + 1] - e->class_begin[c];
+    if (n > 0 && seq_group_of_class(e, c, n) < 0)
+      return false;
+  }
+  return true;
+}
+
+// one window on the device: the pipelined launches, or - domains with classes that have no such instance (teams,
+// workgroup-wide groups) - the frames one after the other through the ordinary launches, same buffers either way
+static int launch_window(lk_engine *e, bool force_safe_flavour) {
+  lk_engine::SeqWindow &w = e->seq;
+  const int S = e->S, n = w.n_frames, R = (int)e->ring.size();
+  const DevImage &u0 = w.und_slot >= 0 ? e->ring[(size_t)w.und_slot] : e->img[LK_IMG_UND];
+  auto def_of = [&](int i) -> DevImage & { return e->ring[(size_t)((w.first_slot + i) % R)]; };
+  auto und_of = [&](int i) -> const DevImage & { return (w.reference_previous && i > 0) ? def_of(i - 1) : u0; };
+  if (e->timing)
+    HIPCHK(hipEventRecord(e->ev_s0, e->stream));
+  if (!w.pipelined) {
+    // the one-pair loop on the device: images of frame i in the pair slots, guess, solve, records to their row
+    DevImage keep_und = e->img[LK_IMG_UND], keep_def = e->img[LK_IMG_DEF];
+    int rc = LK_ERROR_NONE;
+    for (int i = 0; i < n && !rc; ++i) {
+      e->img[LK_IMG_UND] = und_of(i);
+      e->img[LK_IMG_DEF] = def_of(i);
+      e->lv_dirty = true;
+      rc = refresh_level_views(e);
+      if (!rc && i > 0) {
+        const float gg[6] = {0, 0, 0, 0, 0, 0};
+        if (lk_launch_guess(e->d_center.p, e->d_last_p.p, e->d_prev_p.p, e->d_guess.p, gg, 0.f, 0.f, S, e->cfg.fitting_model, 1,
+                            w.velocity, e->stream) != hipSuccess)
+          rc = e->fail(LK_ERROR_DEVICE, "lk_correlate_sequence: guess launch failed");
+      }
+      if (!rc && w.want_guesses && hipMemcpyAsync(e->d_seq_guess.p + (size_t)i * 6 * (size_t)S, e->d_guess.p, 6 * (size_t)S * sizeof(float),
+                                                 hipMemcpyDeviceToDevice, e->stream) != hipSuccess)
+        rc = e->fail(LK_ERROR_DEVICE, "lk_correlate_sequence: guess copy failed");
+      const bool timing = e->timing;
+      e->timing = false; // (the window's own events bracket all frames)
+      if (!rc)
+        rc = launch_all(e, e->d_guess.p, e->d_seq_result.p + (size_t)i * (size_t)S);
+      e->timing = timing;
+      if (!rc && hipMemcpyAsync(e->d_seq_stats.p + (size_t)i * 4 * (size_t)S, e->d_stats.p, 4 * (size_t)S * sizeof(uint32_t),
+                                hipMemcpyDeviceToDevice, e->stream) != hipSuccess)
+        rc = e->fail(LK_ERROR_DEVICE, "lk_correlate_sequence: stats copy failed");
+    }
+    e->img[LK_IMG_UND] = keep_und;
+    e->img[LK_IMG_DEF] = keep_def;
+    e->lv_dirty = true;
+    if (rc)
+      return rc;
+  } else {
+    // per-frame image table, chain and flags of this window
+    std::vector<LkSeqFrame> table((size_t)n);
+    for (int i = 0; i < n; ++i) {
+      const DevImage &u = und_of(i), &d = def_of(i);
+      for (int l = 0; l < LK_MAX_LEVELS; ++l) {
+        table[(size_t)i].und[l] = l <= e->cfg.py_stop ? u.lvl[l] : nullptr;
+        table[(size_t)i].def[l] = l <= e->cfg.py_stop ? d.lvl[l] : nullptr;
+      }
+    }
+    HIPCHK(hipMemcpyAsync(e->d_seq_img.p, table.data(), table.size() * sizeof(LkSeqFrame), hipMemcpyHostToDevice, e->stream)); // (pageable: staged before it returns)
+    HIPCHK(hipMemsetAsync(e->d_seq_chain.p, 0, (size_t)S * kLkSeqChainWords * sizeof(unsigned long long), e->stream));
+    HIPCHK(hipMemsetAsync(e->d_seq_flags.p, 0, 4 * sizeof(uint32_t), e->stream));
+    int n_classes = 0, n_launched = 0;
+    for (int c = 0; c < kNumClasses; ++c)
+      n_classes += e->class_begin[c + 1] > e->class_begin[c];
+    if (n_classes > 1) { // classes are independent sector sets: side by side, as in launch_all
+      if (!e->ev_fork)
+        HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+      HIPCHK(hipEventRecord(e->ev_fork, e->stream));
+    }
+    for (int c = 0; c < kNumClasses; ++c) {
+      const int nc = e->class_begin[c + 1] - e->class_begin[c];
+      if (nc <= 0)
+        continue;
+      hipStream_t st = e->stream;
+      if (n_launched > 0) {
+        if (!e->class_stream[c]) {
+          HIPCHK(hipStreamCreateWithFlags(&e->class_stream[c], hipStreamNonBlocking));
+          HIPCHK(hipEventCreateWithFlags(&e->ev_join[c], hipEventDisableTiming));
+        }
+        st = e->class_stream[c];
+        HIPCHK(hipStreamWaitEvent(st, e->ev_fork, 0));
+      }
+      LkSolveArgs a = base_args(e, e->d_guess.p, e->d_seq_result.p);
+      a.stats = e->d_seq_stats.p;
+      a.order = e->d_order.p + e->class_begin[c];
+      a.n_sectors = nc;
+      a.queue = e->d_queue.p + 8 * c;
+      a.solo = 0;
+      a.seq_frames = n;
+      a.seq_velocity = w.velocity;
+      a.seq_stride = S;
+      a.seq_img = e->d_seq_img.p;
+      a.seq_chain = e->d_seq_chain.p;
+      a.seq_prev_p = e->d_prev_p.p;
+      a.seq_prev_p_out = e->d_prev_p_alt.p;
+      a.seq_guess_out = w.want_guesses ? e->d_seq_guess.p : nullptr;
+      a.seq_flags = e->d_seq_flags.p;
+      int flavour = (force_safe_flavour || safe_flavour(e) || e->class_starved[c]) ? 1 : 0;
+      if (e->reference_order > 0) {
+        flavour = 2;
+        a.reference_order = e->reference_order;
+        a.mark_stale = 1;
+      }
+      a.safe = flavour != 0;
+      HIPCHK(lk_launch_solve_seq(a, e->cfg.fitting_model, e->cfg.interpolation, seq_group_of_class(e, c, nc), flavour, st));
+      if (st != e->stream) {
+        HIPCHK(hipEventRecord(e->ev_join[c], st));
+        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join[c], 0));
+      }
+      ++n_launched;
+    }
+    // reference-order mode: the stale iteration counts, in the order the reference solves - frame by frame, sector by
+    // sector, which IS the layout of the window's records
+    if (e->reference_order > 0 && !e->defer_stale) {
+      int rc = stale_iterations(e, e->d_seq_result.p, n * S);
+      if (rc)
+        return rc;
+    }
+    HIPCHK(hipMemcpyAsync(e->h_seq_flags, e->d_seq_flags.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+  }
+  if (e->timing) {
+    HIPCHK(hipEventRecord(e->ev_s1, e->stream));
+    e->solve_timed = true;
+  }
+  if (w.want_host)
+    HIPCHK(hipMemcpyAsync(e->h_seq_results, e->d_seq_result.p, (size_t)n * (size_t)S * sizeof(lk_result), hipMemcpyDeviceToHost,
+                          e->stream));
+  HIPCHK(hipEventRecord(e->ev_seq, e->stream));
+  e->stats_valid = false;
+  e->stats_frames = n;
+  return LK_ERROR_NONE;
+}
+
+int lk_correlate_sequence_async(lk_engine *e, int und_slot, int first_slot, int n_frames, int reference_previous,
+                                int constant_velocity, int flags) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (e->seq.outstanding || e->results_pending)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_correlate_sequence_async: the previous solve has not been waited for");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const int R = (int)e->ring.size();
+  if (n_frames < 1 || n_frames > R || first_slot < 0 || first_slot >= R || und_slot >= R)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_correlate_sequence_async: the window does not fit the ring (lk_sequence_reserve)");
+  if (und_slot < 0 && !e->img[LK_IMG_UND].valid)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_correlate_sequence_async: no undeformed image");
+  if (!e->committed)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "sectors are not committed (call lk_commit_sectors)");
+  if (e->recommit_pending) {
+    e->recommit_pending = false;
+    int rc = commit_impl(e, true);
+    if (rc)
+      return rc;
+  }
+  if (e->classes_dirty) {
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int rc = classify_sectors(e);
+    if (rc)
+      return rc;
+  }
+  lk_engine::SeqWindow &w = e->seq;
+  w.und_slot = und_slot;
+  w.first_slot = first_slot;
+  w.n_frames = n_frames;
+  w.reference_previous = reference_previous != 0;
+  w.velocity = constant_velocity != 0;
+  w.want_host = (flags & 1) != 0;
+  w.want_guesses = (flags & 2) != 0;
+  w.pipelined = seq_pipelinable(e);
+  const int S = e->S;
+  // (held until this window's done-event is on the stream: a concurrent lk_sequence_set_frame into one of its slots waits for it)
+  std::unique_lock<std::mutex> ring_lock(e->nxt_mu);
+  {
+    // the frames of the window: built, of one geometry, and visible to the solve stream
+    const DevImage &u0 = und_slot >= 0 ? e->ring[(size_t)und_slot] : e->img[LK_IMG_UND];
+    if (!u0.valid)
+      return e->fail(LK_ERROR_BAD_DOMAIN, "lk_correlate_sequence_async: the undeformed frame's ring slot is empty");
+    for (int i = 0; i < n_frames; ++i) {
+      const size_t slot = (size_t)((first_slot + i) % R);
+      const DevImage &d = e->ring[slot];
+      if (!d.valid || d.rows != u0.rows || d.cols != u0.cols)
+        return e->fail(LK_ERROR_BAD_DOMAIN, "lk_correlate_sequence_async: empty ring slot, or frames of different sizes");
+      if (e->ring_fresh[slot]) {
+        HIPCHK(hipStreamWaitEvent(e->stream, e->ring_ready[slot], 0));
+        e->ring_fresh[slot] = 0;
+      }
+      e->ring_window[slot] = e->seq_windows + 1;
+    }
+    if (und_slot >= 0) {
+      if (e->ring_fresh[(size_t)und_slot]) {
+        HIPCHK(hipStreamWaitEvent(e->stream, e->ring_ready[(size_t)und_slot], 0));
+        e->ring_fresh[(size_t)und_slot] = 0;
+      }
+      e->ring_window[(size_t)und_slot] = e->seq_windows + 1;
+    }
+  }
+  HIPCHK(e->d_seq_result.ensure((size_t)n_frames * (size_t)S));
+  HIPCHK(e->d_seq_stats.ensure((size_t)n_frames * 4 * (size_t)S));
+  if (w.want_guesses)
+    HIPCHK(e->d_seq_guess.ensure((size_t)n_frames * 6 * (size_t)S));
+  HIPCHK(e->d_seq_chain.ensure((size_t)S * kLkSeqChainWords));
+  HIPCHK(e->d_seq_img.ensure((size_t)n_frames));
+  HIPCHK(e->d_seq_flags.ensure(4));
+  HIPCHK(e->d_prev_p_alt.ensure(6 * (size_t)S));
+  if (!e->h_seq_flags)
+    HIPCHK(hipHostMalloc((void **)&e->h_seq_flags, 4 * sizeof(uint32_t), hipHostMallocDefault));
+  std::memset(e->h_seq_flags, 0, 4 * sizeof(uint32_t));
+  if (w.want_host && e->h_seq_results_n < (size_t)n_frames * (size_t)S) {
+    if (e->h_seq_results)
+      HIPCHK(hipHostFree(e->h_seq_results));
+    e->h_seq_results = nullptr;
+    e->h_seq_results_n = 0;
+    HIPCHK(hipHostMalloc((void **)&e->h_seq_results, (size_t)n_frames * (size_t)S * sizeof(lk_result), hipHostMallocDefault));
+    e->h_seq_results_n = (size_t)n_frames * (size_t)S;
+  }
+  if (!e->ev_seq)
+    HIPCHK(hipEventCreateWithFlags(&e->ev_seq, hipEventDisableTiming));
+  for (hipEvent_t &ev : e->seq_done)
+    if (!ev)
+      HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  if (w.pipelined) {
+    // the level table: lists, rectangles and geometry (the images come from the per-frame table)
+    DevImage keep_und = e->img[LK_IMG_UND], keep_def = e->img[LK_IMG_DEF];
+    e->img[LK_IMG_UND] = und_slot >= 0 ? e->ring[(size_t)und_slot] : e->img[LK_IMG_UND];
+    e->img[LK_IMG_DEF] = e->ring[(size_t)first_slot];
+    e->lv_dirty = true;
+    int rc = refresh_level_views(e);
+    e->img[LK_IMG_UND] = keep_und;
+    e->img[LK_IMG_DEF] = keep_def;
+    e->lv_dirty = true;
+    if (rc)
+      return rc;
+  }
+  Range range_("lk:solve window");
+  int rc = launch_window(e, false);
+  if (rc)
+    return rc;
+  HIPCHK(hipEventRecord(e->seq_done[e->seq_windows % 4], e->stream));
+  ++e->seq_windows;
+  ring_lock.unlock();
+  w.outstanding = true;
+  return LK_ERROR_NONE;
+}
+
+int lk_wait_sequence(lk_engine *e, lk_result *out) {
+  Range range_("lk:gather window records");
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  lk_engine::SeqWindow &w = e->seq;
+  if (!w.outstanding)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_wait_sequence: no window outstanding");
+  if (out && !w.want_host)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_wait_sequence: the window was launched without host records (flags & 1)");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipEventSynchronize(e->ev_seq));
+  w.outstanding = false;
+  const int S = e->S, n = w.n_frames;
+  if (w.pipelined) {
+    if (e->h_seq_flags[0] != 0u)
+      return e->fail(LK_ERROR_DEVICE, "lk_wait_sequence: a sector's wait for its previous frame ran into its bound - the window is void");
+    if (e->h_seq_flags[1] != 0u) {
+      // a bad pivot in the fast flavour: the whole window again with the SAFE instances (same guesses, same history -
+      // the sequence state is only committed below)
+      int rc = launch_window(e, true);
+      if (rc)
+        return rc;
+      HIPCHK(hipEventRecord(e->seq_done[(e->seq_windows + 3) % 4], e->stream)); // (this window's event, again)
+      HIPCHK(hipEventSynchronize(e->ev_seq));
+      if (e->h_seq_flags[0] != 0u)
+        return e->fail(LK_ERROR_DEVICE, "lk_wait_sequence: a sector's wait for its previous frame ran into its bound - the window is void");
+    }
+    // commit the sequence state: previous_resulting_parameters (the last frame but one), the engine's own record buffer
+    if (n >= 2)
+      HIPCHK(hipMemcpyAsync(e->d_prev_p.p, e->d_prev_p_alt.p, 6 * (size_t)S * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_result.p, e->d_seq_result.p + (size_t)(n - 1) * (size_t)S, (size_t)S * sizeof(lk_result),
+                          hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_stats.p, e->d_seq_stats.p + (size_t)(n - 1) * 4 * (size_t)S, 4 * (size_t)S * sizeof(uint32_t),
+                          hipMemcpyDeviceToDevice, e->stream));
+  } else {
+    HIPCHK(hipMemcpyAsync(e->d_result.p, e->d_seq_result.p + (size_t)(n - 1) * (size_t)S, (size_t)S * sizeof(lk_result),
+                          hipMemcpyDeviceToDevice, e->stream));
+  }
+  if (out)
+    std::memcpy(out, e->h_seq_results, (size_t)n * (size_t)S * sizeof(lk_result));
+  return LK_ERROR_NONE;
+}
+
+int lk_get_sequence_results_device(lk_engine *e, const void **d_records, const void **d_guesses) {
+  if (!e)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!e->d_seq_result.p)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_sequence_results_device: no window was solved");
+  if (d_records)
+    *d_records = e->d_seq_result.p;
+  if (d_guesses)
+    *d_guesses = e->d_seq_guess.p;
+  return LK_ERROR_NONE;
+}
+
+int lk_sequence_is_pipelined(lk_engine *e) { return e && e->seq.pipelined ? 1 : 0; }
+
+int lk_get_sequence_guesses(lk_engine *e, float *out) {
+  if (!e || !out)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!e->seq.want_guesses || e->seq.outstanding || !e->d_seq_guess.p)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_get_sequence_guesses: the last window kept no guesses (flags & 2), or is still outstanding");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipMemcpyAsync(out, e->d_seq_guess.p, (size_t)e->seq.n_frames * 6 * (size_t)e->S * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   return LK_ERROR_NONE;
 }
@@ -2731,15 +3191,17 @@ int lk_get_stats(lk_engine *e, lk_stats *out) {
   HIPCHK(hipSetDevice(e->cfg.device));
   HIPCHK(hipStreamSynchronize(e->stream));
   if (!e->stats_valid && e->committed) {
-    std::vector<uint32_t> h(4 * (size_t)e->S);
-    HIPCHK(hipMemcpy(h.data(), e->d_stats.p, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    // (after a frame-pipelined window: the counters of all its frames)
+    const size_t rows = (size_t)e->S * (size_t)(e->stats_frames > 1 ? e->stats_frames : 1);
+    std::vector<uint32_t> h(4 * rows);
+    HIPCHK(hipMemcpy(h.data(), e->stats_frames > 1 ? e->d_seq_stats.p : e->d_stats.p, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     lk_stats s{};
-    s.sectors = (uint64_t)e->S;
-    for (int i = 0; i < e->S; ++i) {
-      s.evaluations += h[4 * (size_t)i];
-      s.sample_evaluations += h[4 * (size_t)i + 1];
-      s.point_iterations += h[4 * (size_t)i + 2];
-      s.ill_conditioned_solves += h[4 * (size_t)i + 3];
+    s.sectors = (uint64_t)rows;
+    for (size_t i = 0; i < rows; ++i) {
+      s.evaluations += h[4 * i];
+      s.sample_evaluations += h[4 * i + 1];
+      s.point_iterations += h[4 * i + 2];
+      s.ill_conditioned_solves += h[4 * i + 3];
     }
     // 25 B per sample-evaluation + 196 B per evaluation
     s.algorithmic_bytes = 25ull * s.sample_evaluations + 196ull * s.evaluations;

@@ -1853,7 +1853,7 @@ template <int P> __device__ __forceinline__ void translate(float (&p)[6], int sr
 // resident group a queue cannot balance anything (it only leaves half-empty wavefronts
 // behind); then one wavefront per 64/GROUP sectors is launched and the hardware dispatcher
 // fills freed slots with whole wavefronts (measured on C2: 0.33 vs 0.37 ms).
-enum : int { PH_EVAL0 = 0, PH_TENT = 1, PH_REEVAL = 2, PH_FETCH = 3, PH_EXIT = 4 };
+enum : int { PH_EVAL0 = 0, PH_TENT = 1, PH_REEVAL = 2, PH_FETCH = 3, PH_EXIT = 4, PH_WAIT = 5 }; // PH_WAIT: SEQ instances, see below
 constexpr int kStaleIterations = (int)0x80000000; // marker in lk_result.iterations, see lk_stale_iterations_kernel
 
 // Per-sector state that is only touched between evaluations ("cold": last-good parameters,
@@ -1929,9 +1929,20 @@ __device__ unsigned long long g_lk_trace[8 * 16384];
 #endif
 // REF: the reference-order instances (lk_set_reference_order) - SAFE, one wavefront per workgroup, a 16-lane row
 // (four sectors per wavefront, lanes dealt by need: evaluate_ordered_flat) or a wavefront per sector.
-template <int MODEL, int INTERP, int GROUP, int THREADS, bool SAFE, bool REF = false>
+// SEQ: the frame-pipelined instances (lk_correlate_sequence*; LkSolveArgs::seq_*).  A sequence with the Eulerian description
+// solves the SAME sectors on frame after frame, and the guess of frame f + 1 of a sector depends on that sector's own results
+// alone (manager_class.cpp:2677-2686) - nothing in it waits for any other sector of frame f.  One launch per pair therefore
+// pays the straggler tail of every pair (a launch lasts as long as its slowest sector while half of the chip idles).  Here
+// the tickets of the persistent queue are (frame, sector) pairs of a whole window of resident frames, drawn frame-major, and
+// a per-sector chain of 8-byte granules hands the returned parameters from frame to frame (PH_WAIT polls it once per step
+// of the wavefront, without holding the other sectors of the wavefront up).  Arithmetic per (frame, sector) is exactly the
+// one-pair instances': SAFE flavour (the QR inside the kernel, no second pass), fixed lane groups (no solo / adaptive
+// width), and - 16-lane groups, !REF - the starved levels of a sector solved in the same kernel by the finisher's
+// arithmetic (reference-order sums by row_newbcast + the QR, bit-identical to the one-lane kernel), chosen per row.
+template <int MODEL, int INTERP, int GROUP, int THREADS, bool SAFE, bool REF = false, bool SEQ = false>
 __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAFE && !REF ? 4 : LK_MIN_WAVES) : THREADS == 512 ? LK_MIN_WAVES_512 : 1)) lk_solve_kernel(LkSolveArgs a) {
   static_assert(!REF || (SAFE && ((THREADS == kWave && (GROUP == 16 || GROUP == kWave)) || (THREADS == 512 && GROUP == 512))), "reference-order instances");
+  static_assert(!SEQ || (THREADS == kWave && GROUP >= 16 && GROUP <= kWave), "frame-pipelined instances: one wavefront per workgroup");
   constexpr int P = n_params(MODEL);
   using SumsT = Sums<P>;
   constexpr bool COLD_IN_LDS = GROUP > 1 && GROUP <= kWave;
@@ -2012,6 +2023,11 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
   SumsT S;
   bool wide = false; // GROUP == 32 only: both halves of the wavefront work on one sector
   int width = 16;    // GROUP == 16 only: lanes per sector right now (16 / 32 / 64), wavefront-uniform
+  int cur_frame = 0; // SEQ: the frame (of the window) this group's sector is being solved on
+  uint32_t wait_spins = 0; // SEQ: rounds in which every group of the wavefront was waiting for its sector's previous frame
+  // SEQ, 16-lane rows, not the reference-order instance: a level with at most starved_max samples is solved with the
+  // finisher's arithmetic, row by row (the one-pair chain: one-lane kernel -> finisher -> lane groups, in one kernel)
+  constexpr bool UNIFIED = SEQ && !REF && SAFE && GROUP == 16;
   TeamCtx team;
   if constexpr (GROUP == 512) {
     if (a.team_w > 1) {
@@ -2069,9 +2085,15 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
     c.ry = rc.y;
     c.rw = rc.z;
     c.n = rc.z > 0 ? rc.w : (int)(lv.off[k.s + 1] - off);
-    c.und = (gptr<uint8_t>)lv.und;
-    c.def = (gptr<uint8_t>)lv.def;
-    c.xy = (gptr<f32x2>)((!starved && lv.xy_eval ? lv.xy_eval : lv.xy) + off); // (unordered sums: the row-major copy)
+    if constexpr (SEQ) { // the images of this sector's frame (same geometry, same lists)
+      c.und = (gptr<uint8_t>)a.seq_img[cur_frame].und[k.level];
+      c.def = (gptr<uint8_t>)a.seq_img[cur_frame].def[k.level];
+    } else {
+      c.und = (gptr<uint8_t>)lv.und;
+      c.def = (gptr<uint8_t>)lv.def;
+    }
+    const bool level_ordered = starved || (UNIFIED && c.n <= a.starved_max); // sums in the reference's order: its list
+    c.xy = (gptr<f32x2>)((!level_ordered && lv.xy_eval ? lv.xy_eval : lv.xy) + off); // (unordered sums: the row-major copy)
     c.urows = lv.urows;
     c.ucols = lv.ucols;
     c.drows = lv.drows;
@@ -2136,23 +2158,38 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
       r.errorCode = k.error;
       r.undCenterX = k.c0x;
       r.undCenterY = k.c0y;
-      a.result[k.s] = r;
-      if (a.last_p) {
+      // SEQ: one record and one stats row per frame; the sequence state (last_p, last_eval_p) is written by the
+      // window's LAST frame only - the frames of a sector run on whatever CU drew them, and two XCDs' write-back
+      // copies of one address have no order
+      const size_t ridx = SEQ ? (size_t)cur_frame * (size_t)a.seq_stride + (size_t)k.s : (size_t)k.s;
+      const bool state_out = !SEQ || cur_frame == a.seq_frames - 1;
+      a.result[ridx] = r;
+      if (a.last_p && state_out) {
 #pragma unroll
         for (int i = 0; i < 6; ++i)
           a.last_p[(size_t)k.s * 6 + i] = r.resultingParameters[i];
       }
-      if (a.last_eval_p) { // def_xy_positions of the last level-0 evaluation (getDefXY0, :884-896);
-                           // with py_start > 0 the reference re-applies the returned parameters
+      if (a.last_eval_p && state_out) { // def_xy_positions of the last level-0 evaluation (getDefXY0, :884-896);
+                                        // with py_start > 0 the reference re-applies the returned parameters
 #pragma unroll
         for (int i = 0; i < 6; ++i)
           a.last_eval_p[(size_t)k.s * 6 + i] = a.py_start == 0 ? evaluated[i] : r.resultingParameters[i];
       }
       if (a.stats) {
-        a.stats[(size_t)k.s * 4 + 0] = k.n_evals;
-        a.stats[(size_t)k.s * 4 + 1] = k.n_sample_evals;
-        a.stats[(size_t)k.s * 4 + 2] = k.n_point_iters;
-        a.stats[(size_t)k.s * 4 + 3] = k.n_ill;
+        a.stats[ridx * 4 + 0] = k.n_evals;
+        a.stats[ridx * 4 + 1] = k.n_sample_evals;
+        a.stats[ridx * 4 + 2] = k.n_point_iters;
+        a.stats[ridx * 4 + 3] = k.n_ill;
+      }
+      if constexpr (SEQ) {
+        // hand the returned parameters to the sector's next frame: granules {frame + 1, bits}, write-through, the tag
+        // IS the flag (lk_device.hpp: kLkSeqChainWords)
+        unsigned long long *ch = a.seq_chain + (size_t)k.s * kLkSeqChainWords + (size_t)(cur_frame & 1) * 8;
+        const unsigned long long tag = (unsigned long long)(uint32_t)(cur_frame + 1) << 32;
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+          __hip_atomic_store(ch + i, tag | (unsigned long long)__float_as_uint(r.resultingParameters[i]), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
       }
       if (starved && a.handoff) {
         LkHandoff h{};
@@ -2216,7 +2253,24 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
         slot = __shfl(slot, ((int)threadIdx.x & 63) & ~(GROUP - 1), 64);
       }
       steps = 0;
-      if (finisher || a.resume) { // resume a sector an earlier launch parked in the middle of a level
+      if constexpr (SEQ) { // ticket -> (frame, sector), frame-major; the solve starts when the sector's previous frame is in
+        if (slot < a.n_sectors * a.seq_frames) {
+          Cold k{};
+          cur_frame = slot / a.n_sectors; // (once per sector and frame)
+          const int pos = slot - cur_frame * a.n_sectors;
+          k.s = a.order ? (int)a.order[pos] : pos;
+          const float2 c0 = a.center[k.s];
+          k.c0x = c0.x;
+          k.c0y = c0.y;
+          k.use_saved = 1;
+          k.level = a.py_stop;
+          k.level_old = 0;
+          cold.store(cold_slot, k);
+          phase = PH_WAIT;
+        } else {
+          phase = PH_EXIT;
+        }
+      } else if (finisher || a.resume) { // resume a sector an earlier launch parked in the middle of a level
         if (a.resume && !finisher && (int)threadIdx.x % GROUP == 0 &&
             slot == n_parked + (int)gridDim.x * (THREADS / GROUP) - 1) {
           // every group draws exactly one ticket past the end of the list; whoever draws the last
@@ -2282,7 +2336,93 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
 #if defined(LK_TRACE_FINE) && !defined(LK_TRACE_TRANS)
     tr_fetch += __builtin_amdgcn_s_memtime() - tr_f0;
 #endif
+    if constexpr (SEQ) {
+      if (phase == PH_WAIT) {
+        // Has frame cur_frame - 1 of this sector published its parameters?  One look per step of the wavefront: the
+        // other groups of the wavefront go on solving meanwhile.  r = p(f-1), q = p(f-2) (frame 1 of the window: the
+        // previous_resulting_parameters the host-side guess of frame 0 left); the guess is lk_guess_kernel's,
+        // operation for operation (manager_class.cpp:2677-2699).
+        Cold k = cold.load(cold_slot);
+        bool ready = true;
+        float g[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+          g[i] = 0.f;
+        if (cur_frame == 0) {
+#pragma unroll
+          for (int i = 0; i < P; ++i)
+            g[i] = a.guess[(size_t)k.s * 6 + i];
+        } else {
+          const unsigned long long *ch = a.seq_chain + (size_t)k.s * kLkSeqChainWords;
+          const unsigned long long *chr = ch + (size_t)((cur_frame - 1) & 1) * 8, *chq = ch + (size_t)(cur_frame & 1) * 8;
+          float r[P], q[P];
+#pragma unroll
+          for (int i = 0; i < P; ++i) {
+            const unsigned long long x = __hip_atomic_load(chr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ready = ready && (uint32_t)(x >> 32) == (uint32_t)cur_frame;
+            r[i] = __uint_as_float((uint32_t)x);
+            q[i] = r[i];
+          }
+          if (a.seq_velocity) {
+            if (cur_frame == 1) {
+#pragma unroll
+              for (int i = 0; i < P; ++i)
+                q[i] = a.seq_prev_p[(size_t)k.s * 6 + i];
+            } else {
+#pragma unroll
+              for (int i = 0; i < P; ++i) {
+                const unsigned long long x = __hip_atomic_load(chq + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ready = ready && (uint32_t)(x >> 32) == (uint32_t)(cur_frame - 1);
+                q[i] = __uint_as_float((uint32_t)x);
+              }
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < P; ++i)
+            g[i] = a.seq_velocity ? r[i] + (r[i] - q[i]) : r[i];
+          // previous_resulting_parameters after the window = p of its last frame but one (what the next guess reads)
+          if (ready && cur_frame == a.seq_frames - 1 && a.seq_prev_p_out && (int)threadIdx.x % GROUP == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+              a.seq_prev_p_out[(size_t)k.s * 6 + i] = i < P ? r[i] : 0.f;
+          }
+        }
+        if (ready) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+            p[i] = g[i];
+          if (a.seq_guess_out && (int)threadIdx.x % GROUP == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+              a.seq_guess_out[((size_t)cur_frame * (size_t)a.seq_stride + (size_t)k.s) * 6 + i] = g[i];
+          }
+          enter_level(k);
+          cold.store(cold_slot, k);
+        }
+      }
+    }
     bool active = phase < PH_FETCH;
+    if constexpr (SEQ) {
+      // Nobody in this wavefront can go on: every group waits for a frame another wavefront is solving.  Sleep and look
+      // again; bounded - a wait that never ends (it cannot: every awaited ticket was drawn by a running wavefront) or
+      // another wavefront's give-up voids the launch (seq_flags[0]) and lets the grid drain.
+      const unsigned long long waiting = __ballot(phase == PH_WAIT);
+      if (__ballot(active) == 0ull && waiting != 0ull) {
+        ++wait_spins;
+        const bool give_up = wait_spins > (1u << 20);
+        if (give_up || (wait_spins & 255u) == 0u) {
+          if (give_up || __hip_atomic_load(a.seq_flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            if (((int)threadIdx.x & 63) == 0)
+              __hip_atomic_store(a.seq_flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+          }
+        }
+        __builtin_amdgcn_s_sleep(16);
+        continue;
+      }
+      if (waiting != ~0ull)
+        wait_spins = 0;
+    }
     if constexpr (GROUP >= kWave) {
       if (!active) {
         if (phase == PH_FETCH)
@@ -2399,6 +2539,14 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
     LevelCtx ce = c;
     if (!active)
       ce.n = 0;
+    // UNIFIED: rows at a starved level take the finisher's evaluation (ordered sums), the others the lane-parallel one;
+    // rows without work follow whatever the working rows do (both paths cost their instructions once per wavefront)
+    bool row_ordered = finisher;
+    if constexpr (UNIFIED) {
+      const bool ord = active && c.n <= a.starved_max;
+      const bool any_plain = __ballot(active && !ord) != 0ull;
+      row_ordered = active ? ord : !any_plain;
+    }
 #ifdef LK_TRACE
     const unsigned long long tr_e0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -2424,7 +2572,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
       err = a.reference_order > 1 ? evaluate_ordered<MODEL, INTERP, GROUP, true>(ce, p, S, ord_lds, a.reference_order)
                                   : evaluate_ordered<MODEL, INTERP, GROUP, false>(ce, p, S, ord_lds, 1);
     } else {
-      err = evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds, &team, wide, finisher, GROUP == 16 ? width : 0);
+      err = evaluate<MODEL, INTERP, GROUP, THREADS>(ce, p, S, lds, &team, wide, row_ordered, GROUP == 16 ? width : 0);
     }
 #ifdef LK_TRACE
     tr_eval += __builtin_amdgcn_s_memtime() - tr_e0;
@@ -2521,12 +2669,20 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
 #ifdef LK_TRACE
         const unsigned long long tr_s0 = __builtin_amdgcn_s_memtime();
 #endif
-        const bool wc = damped_step<P, SAFE || STARVED>(S, lam_use, c.scaling, p, starved, nullptr, SAFE && GROUP >= 16 && GROUP <= kWave); // p += dp
+        const bool step_starved = starved || (UNIFIED && row_ordered); // (an active row's own flag: see row_ordered)
+        const bool wc = damped_step<P, SAFE || STARVED>(S, lam_use, c.scaling, p, step_starved, nullptr, SAFE && GROUP >= 16 && GROUP <= kWave); // p += dp
 #ifdef LK_TRACE
         tr_solve += __builtin_amdgcn_s_memtime() - tr_s0;
 #endif
-        if (!wc && !starved)
+        if (!wc && !step_starved)
           ++k.n_ill;
+        if constexpr (SEQ && !SAFE) {
+          // fast flavour inside a window: there is no second pass to hand the sector to (its next frame waits for this
+          // one).  The step of the bad parameter is zero and the host is told: it solves the window again with the SAFE
+          // instances (never seen on textured images: lk_stats.ill_conditioned_solves is 0 on configs 2 and 5).
+          if (!wc && (int)threadIdx.x % GROUP == 0)
+            __hip_atomic_store(a.seq_flags + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         bool ill_parked = false;
         if constexpr (!SAFE && !STARVED) {
           if (!wc && a.ill_list) {
@@ -3965,6 +4121,93 @@ hipError_t lk_launch_solve(const LkSolveArgs &a, int model, int interp, int grou
   case LK_FM_UVQ: return launch_solve_m<LK_FM_UVQ>(a, interp, group, st);
 #endif
   default: return launch_solve_m<LK_FM_UVUXUYVXVY>(a, interp, group, st);
+  }
+}
+
+// ---- frame-pipelined launches (the SEQ instances) --------------------------------------------------------------
+// One persistent grid per size class for a whole window of frames.  No more groups than the class has sectors (a group
+// beyond that could only wait for a sector's previous frame), no more wavefronts than are resident (more would not
+// hurt - a wavefront that is not running holds no ticket - but would queue behind the grid for nothing).
+template <int MODEL, int INTERP, int GROUP, bool SAFE, bool REF>
+static hipError_t launch_solve_seq_gs(const LkSolveArgs &a, hipStream_t st) {
+  static std::atomic<int> resident_cache{0};
+  int resident = resident_cache.load(std::memory_order_relaxed);
+  if (resident == 0) {
+    resident = resident_workgroups(lk_solve_kernel<MODEL, INTERP, GROUP, kWave, SAFE, REF, true>, kWave);
+    resident_cache.store(resident, std::memory_order_relaxed);
+  }
+  const int per_wg = kWave / GROUP;
+  const int want = (a.n_sectors + per_wg - 1) / per_wg;
+  LkSolveArgs b = a;
+  b.persistent = 1;
+  b.chunk = 0;
+  b.team_w = 0;
+  b.solo = 0;
+  int grid = want < resident ? want : resident;
+  static const int grid_permille = [] { // tuning hook: the grid as a share of min(sectors / groups per wavefront, resident)
+    const char *f = getenv("LK_SEQ_GRID");
+    return f ? atoi(f) : 1000;
+  }();
+  grid = (int)((long long)grid * grid_permille / 1000);
+  grid = grid < 1 ? 1 : grid;
+  hipError_t qe = hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st);
+  if (qe != hipSuccess)
+    return qe;
+  hipLaunchKernelGGL((lk_solve_kernel<MODEL, INTERP, GROUP, kWave, SAFE, REF, true>), dim3((unsigned)grid), dim3(kWave), 0, st, b);
+  return hipGetLastError();
+}
+
+// flavour: 0 fast (root-free Cholesky; a bad pivot raises seq_flags[1]), 1 SAFE (the QR inside the kernel; 16-lane rows:
+// starved levels with the finisher's arithmetic), 2 reference order (a.reference_order = T)
+template <int MODEL, int INTERP>
+static hipError_t launch_solve_seq_mi(const LkSolveArgs &a, int group, int flavour, hipStream_t st) {
+  if (flavour == 2) {
+    switch (group) {
+    case 16: return launch_solve_seq_gs<MODEL, INTERP, 16, true, true>(a, st);
+    case 64: return launch_solve_seq_gs<MODEL, INTERP, 64, true, true>(a, st);
+    default: return hipErrorInvalidValue;
+    }
+  }
+  if (flavour == 1) {
+    switch (group) {
+    case 16: return launch_solve_seq_gs<MODEL, INTERP, 16, true, false>(a, st);
+    case 32: return launch_solve_seq_gs<MODEL, INTERP, 32, true, false>(a, st);
+    case 64: return launch_solve_seq_gs<MODEL, INTERP, 64, true, false>(a, st);
+    default: return hipErrorInvalidValue;
+    }
+  }
+  switch (group) {
+  case 16: return launch_solve_seq_gs<MODEL, INTERP, 16, false, false>(a, st);
+  case 32: return launch_solve_seq_gs<MODEL, INTERP, 32, false, false>(a, st);
+  case 64: return launch_solve_seq_gs<MODEL, INTERP, 64, false, false>(a, st);
+  default: return hipErrorInvalidValue;
+  }
+}
+
+template <int MODEL>
+static hipError_t launch_solve_seq_m(const LkSolveArgs &a, int interp, int group, int flavour, hipStream_t st) {
+  switch (interp) {
+#ifndef LK_TUNE_ONLY_AFFINE_BICUBIC
+  case LK_IM_NEAREST: return launch_solve_seq_mi<MODEL, LK_IM_NEAREST>(a, group, flavour, st);
+  case LK_IM_BILINEAR: return launch_solve_seq_mi<MODEL, LK_IM_BILINEAR>(a, group, flavour, st);
+  case LK_IM_BICUBIC_SEPARABLE: return launch_solve_seq_mi<MODEL, LK_IM_BICUBIC_SEPARABLE>(a, group, flavour, st);
+#endif
+  default: return launch_solve_seq_mi<MODEL, LK_IM_BICUBIC>(a, group, flavour, st);
+  }
+}
+
+hipError_t lk_launch_solve_seq(const LkSolveArgs &a, int model, int interp, int group, int flavour, hipStream_t st) {
+  if (a.n_sectors <= 0 || a.seq_frames <= 0)
+    return hipSuccess;
+  if ((long long)a.n_sectors * a.seq_frames >= (1ll << 31) - (1ll << 20)) // (tickets are ints; the grid draws a few past the end)
+    return hipErrorInvalidValue;
+  switch (model) {
+#ifndef LK_TUNE_ONLY_AFFINE_BICUBIC
+  case LK_FM_U: return launch_solve_seq_m<LK_FM_U>(a, interp, group, flavour, st);
+  case LK_FM_UV: return launch_solve_seq_m<LK_FM_UV>(a, interp, group, flavour, st);
+  case LK_FM_UVQ: return launch_solve_seq_m<LK_FM_UVQ>(a, interp, group, flavour, st);
+#endif
+  default: return launch_solve_seq_m<LK_FM_UVUXUYVXVY>(a, interp, group, flavour, st);
   }
 }
 

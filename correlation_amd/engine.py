@@ -260,6 +260,51 @@ class HipCorrelationEngine:
         self._chk(self.lib.lk_wait_results(self._h, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    # ---- frame-pipelined windows (lk_correlate_sequence_async) --------------------------
+    def sequence_reserve(self, n_slots):
+        self._chk(self.lib.lk_sequence_reserve(self._h, int(n_slots)))
+
+    def sequence_set_frame(self, slot, pixels):
+        a = np.ascontiguousarray(pixels, dtype=np.uint8)
+        assert a.ndim == 2
+        self._chk(self.lib.lk_sequence_set_frame(self._h, int(slot), a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1],
+                                                 a.strides[0]))
+
+    def sequence_set_frame_device(self, slot, dev_ptr, rows, cols, step=None):
+        self._chk(self.lib.lk_sequence_set_frame_device(self._h, int(slot), C.c_void_p(dev_ptr), rows, cols,
+                                                        cols if step is None else step))
+
+    def correlate_sequence_async(self, n_frames, first_slot=0, und_slot=-1, reference_previous=False,
+                                 constant_velocity=True, host_records=True, keep_guesses=False):
+        self._seq_frames = int(n_frames)
+        self._chk(self.lib.lk_correlate_sequence_async(self._h, int(und_slot), int(first_slot), int(n_frames),
+                                                       int(bool(reference_previous)), int(bool(constant_velocity)),
+                                                       (1 if host_records else 0) | (2 if keep_guesses else 0)))
+
+    def wait_sequence(self, host_records=True):
+        """records [n_frames][S] of the window (or None when the window keeps them on the device)"""
+        out = np.zeros((self._seq_frames, self.n_sectors), RESULT_DTYPE) if host_records else None
+        self._chk(self.lib.lk_wait_sequence(self._h, out.ctypes.data_as(C.c_void_p) if host_records else None))
+        return out
+
+    def correlate_sequence(self, n_frames, **kw):
+        self.correlate_sequence_async(n_frames, **kw)
+        return self.wait_sequence(kw.get("host_records", True))
+
+    def sequence_results_device(self):
+        r, g = C.c_void_p(), C.c_void_p()
+        self._chk(self.lib.lk_get_sequence_results_device(self._h, C.byref(r), C.byref(g)))
+        return r.value, g.value
+
+    def sequence_guesses(self):
+        g = np.zeros((self._seq_frames, self.n_sectors, 6), np.float32)
+        self._chk(self.lib.lk_get_sequence_guesses(self._h, _ffi.fptr(g)))
+        return g
+
+    @property
+    def sequence_is_pipelined(self):
+        return bool(self.lib.lk_sequence_is_pipelined(self._h))
+
     def adjust_initial_guess(self, frame, constant_velocity, global_guess, global_center):
         g = np.zeros(6, np.float32)
         g[:len(global_guess)] = global_guess

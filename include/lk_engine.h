@@ -276,6 +276,48 @@ int lk_get_results_device(lk_engine *e, const void **d_records);
 int lk_correlate_all_async(lk_engine *e);
 int lk_wait_results(lk_engine *e, lk_result *out);
 
+/* ---- frame-pipelined windows of a sequence ----------------------------------------- */
+/* perform_multiframe_correlation's frame loop (manager_class.cpp:1380-1496) for the Eulerian description: the
+ * sectors stay where they are, every frame brings a new deformed image, and the guess of frame f + 1 of a sector is
+ * a function of that SECTOR's own earlier results (adjust_initial_guess, :2677-2699: p(f), or 2 p(f) - p(f-1) with the
+ * first image as the reference) - it waits for no other sector.  One launch per pair pays the slow tail of every
+ * pair: a launch lasts as long as its slowest sector.  Here K deformed frames are resident at once (a ring of
+ * pyramids, filled on the next-frame stream like LK_IMG_NXT, :1438-1447) and ONE launch per size class solves the
+ * whole window: its work items are (frame, sector) pairs drawn frame-major from a device-wide queue, and a sector's
+ * parameters travel from frame to frame through a per-sector chain in device memory; the group that draws (f, s)
+ * before (f - 1, s) is done waits for it without blocking the other sectors of its wavefront.
+ * Records: the arithmetic of a (frame, sector) is the one-pair kernels' - in batch-invariant and in reference-order
+ * mode the window's records are byte-identical to solving the pairs one after the other with
+ * lk_adjust_initial_guess + lk_correlate_all*.  The default mode uses the fixed lane groups and the fast flavour
+ * inside a window (a window in which a damped system meets a bad pivot is solved again with the SAFE flavour).
+ * Domains with sectors of more than 8192 samples (workgroup-wide groups, teams) have no pipelined instance:
+ * their windows run the frames one after the other on the device - same interface, same records. */
+/* a ring of n_slots resident deformed-frame pyramids (grows; never shrinks) */
+int lk_sequence_reserve(lk_engine *e, int n_slots);
+/* upload + pyramid of one frame into ring slot `slot`, on the next-frame stream: may overlap a running
+ * lk_correlate_* / window (the one concurrent call of section 8b's threading contract); a slot that a window
+ * still reads is overwritten only after that window (stream order on the device) */
+int lk_sequence_set_frame(lk_engine *e, int slot, const uint8_t *host_pixels, int rows, int cols, int step);
+int lk_sequence_set_frame_device(lk_engine *e, int slot, const void *device_pixels, int rows, int cols, int step);
+/* solve frames i = 0 .. n_frames-1 of a window: deformed image = ring slot (first_slot + i) % n_slots; undeformed
+ * image = LK_IMG_UND (und_slot < 0) or ring slot und_slot for frame 0 and, with reference_previous, the previous
+ * frame's deformed image for the others (image roles of manager_class.cpp:1386-1407).  Frame 0 starts from the
+ * engine-held guesses (lk_adjust_initial_guess for that frame of the sequence, or whatever the caller put there),
+ * every later frame from the guess rule above; the sequence state the next lk_adjust_initial_guess reads is left as
+ * n_frames one-pair solves would leave it.  flags: 1 = copy the records to the host (lk_wait_sequence's out),
+ * 2 = keep the guesses every frame started from (lk_get_sequence_results_device).  Does not wait. */
+int lk_correlate_sequence_async(lk_engine *e, int und_slot, int first_slot, int n_frames, int reference_previous,
+                                int constant_velocity, int flags);
+/* block until the window is solved; out: [n_frames][S] records (frame-major) or NULL.  LK_ERROR_DEVICE if the
+ * window is void (a bounded wait inside the kernel gave up: cannot happen unless the device loses wavefronts). */
+int lk_wait_sequence(lk_engine *e, lk_result *out);
+/* the window's records [n_frames][S] and (flags & 2) guesses [n_frames][S][6] in device memory */
+int lk_get_sequence_results_device(lk_engine *e, const void **d_records, const void **d_guesses);
+/* 1: the last window ran on the frame-pipelined instances, 0: frame after frame */
+int lk_sequence_is_pipelined(lk_engine *e);
+/* (flags & 2) the guesses every frame of the last window started from, [n_frames][S][6], to the host */
+int lk_get_sequence_guesses(lk_engine *e, float *guesses);
+
 /* managerClass::adjust_initial_guess (manager_class.cpp:2602-2707), batched on the
  * device for every sector: frame 0 -> global guess + strain*(sector centre - global
  * centre); later frames -> constant_velocity ? 2*p_prev - p_prevprev : p_prev, where
