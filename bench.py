@@ -243,6 +243,100 @@ def other_configs(ca):
     return out
 
 
+def sequence_frames(ca, torch, dev, size, n_frames):
+    """the 64-pair synthetic sequence of BASELINE config 4 (constant velocity (0.8, -0.4) px / frame + 1e-4 / frame dilation),
+    rendered on the GPU, resident in HBM as one [n_frames + 1, H, W] u8 tensor"""
+    frames = ca.speckle.speckle_sequence(size, size, n_frames + 1, velocity=(0.8, -0.4), dilation=1e-4, seed=7, device=str(dev))
+    return torch.from_numpy(np.stack(frames)).to(dev)
+
+
+def sequence_block(ca, torch, dev, wl, d_frames, mode, repeats=3, check_loop=True):
+    """A tracked SEQUENCE of `wl`'s sector grid (BASELINE config 4 is one; Eulerian description, first image as the
+    reference, constant-velocity guesses, manager_class.cpp:1380-1496, :2677-2699), frames resident in HBM.
+    `window`: all pairs in ONE frame-pipelined window (lk_correlate_sequence_async: every sector advances through the frames
+    on its own).  `one_pair_at_a_time`: the same sequence as a loop of guess kernel + pyramid + solve launches.
+    ms_per_pair of both includes the pyramid of the pair's new frame and the guesses; kernel_ms_per_pair is the window's
+    solve alone (HIP events on the engine's stream)."""
+    n = int(d_frames.shape[0]) - 1
+    size = int(d_frames.shape[1])
+    c = (size / 2 - 0.5, size / 2 - 0.5)
+    zero = np.zeros(6, np.float32)
+
+    def engine():
+        e = ca.HipCorrelationEngine(fitting_model=wl.model, py_stop=wl.py_stop, device=dev.index or 0)
+        if mode == "reference_order":
+            e.set_reference_order(1)
+        elif mode == "batch_invariant":
+            e.set_batch_invariant(True)
+        e.set_image_device(ca.IMG_UND, d_frames[0].data_ptr(), size, size)
+        e.set_rect_grid(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, wl.hs, wl.vs)
+        e.commit_sectors()
+        return e
+
+    e = engine()
+    e.sequence_reserve(n)
+    wall, kern = [], []
+    for r in range(repeats + 1):
+        e.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):                                       # upload copy + pyramid of every new frame (next-frame stream)
+            e.sequence_set_frame_device(i, d_frames[i + 1].data_ptr(), size, size)
+        e.adjust_initial_guess(0, True, zero, c)
+        e.correlate_sequence_async(n, constant_velocity=True, host_records=False)
+        e.wait_sequence(False)
+        e.synchronize()
+        t1 = time.perf_counter()
+        if r:
+            wall.append((t1 - t0) * 1e3 / n)
+            kern.append(e.stats()["solve_ms"] / n)
+    st = e.stats()
+    pipelined = e.sequence_is_pipelined
+    e.adjust_initial_guess(0, True, zero, c)
+    rec = e.correlate_sequence(n, constant_velocity=True)
+    ms, kms = float(np.median(wall)), float(np.median(kern))
+    out = {"workload": wl.name, "mode": mode, "pairs": n, "sectors": int(rec.shape[1]), "frames_resident": n,
+           "pipelined_instances": bool(pipelined),
+           "window": {"ms_per_pair": ms, "kernel_ms_per_pair": kms,
+                      "point_iterations_per_s": st["point_iterations"] / n / (ms * 1e-3),
+                      "algorithmic_GBps": st["algorithmic_bytes"] / n / (kms * 1e-3) / 1e9,
+                      "frac": st["algorithmic_bytes"] / n / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "algorithmic_bytes_per_pair": st["algorithmic_bytes"] / n,
+                      "evaluations_per_sector_and_pair": st["evaluations"] / st["sectors"],
+                      "error_free_fraction_first_pair": float((rec[0]["error_code"] == 0).mean()),
+                      "error_free_fraction_last_pair": float((rec[-1]["error_code"] == 0).mean())}}
+    vk = profile_constants().get("valu_insts_per_window_pair", {}).get(f"{wl.name.split(':')[0]}_{mode}")
+    if vk:
+        out["window"]["valu_issue_frac"] = valu_issue_frac(vk, kms)
+    if check_loop:
+        a = engine()
+        a.set_timing(False)
+        same, t_loop = 0, 0.0
+        for r in range(2):
+            a.synchronize()
+            t0 = time.perf_counter()
+            got = []
+            for k in range(n):
+                a.set_image_device(ca.IMG_DEF, d_frames[k + 1].data_ptr(), size, size)
+                a.adjust_initial_guess(k, True, zero, c)
+                if r:   # (second pass: the records, for the comparison - outside the timing)
+                    a.correlate_all_async()
+                    got.append(a.wait_results())
+                else:
+                    a.correlate_all_device(0, 0)
+            a.synchronize()
+            if not r:
+                t_loop = (time.perf_counter() - t0) * 1e3 / n
+        same = sum(int(g.tobytes() == rec[k].tobytes()) for k, g in enumerate(got))
+        out["one_pair_at_a_time"] = {"ms_per_pair": t_loop, "frames_with_identical_records": same, "of": n,
+                                     "note": "records of the window against the loop's: identical bytes are required in "
+                                             "reference-order and batch-invariant mode (tests/test_sequence_window_gpu.py); the default "
+                                             "mode's loop widens lane groups by batch composition, its window uses fixed groups"}
+        out["window"]["speedup_vs_one_pair_at_a_time"] = t_loop / ms
+        a.close()
+    e.close()
+    return out
+
+
 def sharded_config(ca, torch, dist, wl, rank, world, local_rank, steps, warmup):
     """One pair of `wl` with its sector grid split over the ranks in contiguous blocks (the code path of
     --workload): per step the deformed frame is broadcast from rank 0 (RCCL over xGMI), every rank builds both
@@ -433,6 +527,8 @@ def main():
     ap.add_argument("--round", type=int, default=3,
                     help="N > 1: steps whose frames travel in one broadcast and whose records leave in one "
                          "all-gather (the host cost of a collective exceeds a step's GPU time)")
+    ap.add_argument("--sequence-frames", type=int, default=64,
+                    help="N = 1: pairs of the `sequence` blocks (configs 2 and 4 as tracked sequences; 0: skip them)")
     ap.add_argument("--overlap", type=int, default=3,
                     help="N = 1: pairs in flight of the extra `overlapped` block (0: skip it)")
     ap.add_argument("--native", action="store_true",
@@ -711,6 +807,24 @@ def main():
         except Exception as ex:   # noqa: BLE001
             end_to_end = {"error": repr(ex)}
 
+    # ---- tracked sequences: configs 2 and 4 as 64-pair sequences, frame-pipelined window against the one-pair loop ----
+    sequence = None
+    if world == 1 and not use_dist and not strong and args.sequence_frames > 1:
+        sequence = {}
+        try:
+            d_frames = sequence_frames(ca, torch, dev, C2.size, args.sequence_frames)
+            for key, w_ in (("C2", C2), ("C4", C4)):
+                sequence[key] = {}
+                for mode in ("default", "reference_order"):
+                    try:
+                        sequence[key][mode] = sequence_block(ca, torch, dev, w_, d_frames, mode)
+                    except Exception as ex:   # noqa: BLE001 - extra evidence must never take the headline line down
+                        sequence[key][mode] = {"error": repr(ex)}
+            del d_frames
+        except Exception as ex:   # noqa: BLE001
+            sequence["error"] = repr(ex)
+        torch.cuda.set_stream(stream)
+
     # ---- multi-GPU configs: one pair with the sector grid split over the ranks (every rank takes part) ----
     sharded = {}
     if not strong and not args.no_sharded_configs:
@@ -799,6 +913,8 @@ def main():
             line["reference_order_mode"] = ref_order
         if end_to_end:
             line["end_to_end"] = end_to_end
+        if sequence:
+            line["sequence"] = sequence
         if sharded:
             line["sharded_configs"] = sharded
         if native is not None:

@@ -2883,6 +2883,24 @@ static int launch_window(lk_engine *e, bool force_safe_flavour) {
         flavour = 2;
         a.reference_order = e->reference_order;
         a.mark_stale = 1;
+      } else if (e->class_starved[c]) {
+        // Sectors that spend most of their evaluations on starved levels (config 4: 7 x 7 samples, 9-16 and 1-4 at levels 1
+        // and 2).  The rows of a wavefront then sit at different levels most of the time: no level alignment (it never
+        // changes a bit; 1.33 -> 1.21 ms per pair).  And in the default mode - whose arithmetic is free within the
+        // reference's noise - such a class takes the reference-order instance with its lanes dealt by need, which IS the
+        // CPU engine's arithmetic and the fastest instance at these sizes (0.98 ms per pair).
+        long long n0 = 0;
+        for (int i = e->class_begin[c]; i < e->class_begin[c + 1]; ++i)
+          n0 += level0_count(e, (int)e->h_order[(size_t)i]);
+        static const int small_n0 = [] { const char *f = std::getenv("LK_SEQ_SMALL"); return f ? std::atoi(f) : 64; }(); // tuning hook
+        if (n0 <= (long long)small_n0 * nc) {
+          a.align = 0;
+          if (!safe_flavour(e) && !force_safe_flavour) {
+            flavour = 2;
+            a.reference_order = 1;
+            a.mark_stale = -1; // (a first evaluation that fails reports 0 iterations, like every default-mode instance)
+          }
+        }
       }
       a.safe = flavour != 0;
       HIPCHK(lk_launch_solve_seq(a, e->cfg.fitting_model, e->cfg.interpolation, seq_group_of_class(e, c, nc), flavour, st));

@@ -2152,7 +2152,8 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
       // reference-order mode: the very first evaluation of the sector failed, so no LM trip ever ran -
       // the reference then reports whatever its reached_iterations member still holds from the sector
       // before (correlation_class.cpp:413-419, :870); lk_stale_iterations_kernel fills that in
-      r.iterations = ((ordered_all || a.mark_stale != 0) && k.n_evals == 1u && k.error != LK_ERROR_NONE && k.lg_chi == FLT_MAX && k.reached == 0)
+      // (mark_stale < 0: a default-mode launch that borrows the reference-order instance - it reports 0 like the default instances)
+      r.iterations = (((ordered_all && a.mark_stale == 0) || a.mark_stale > 0) && k.n_evals == 1u && k.error != LK_ERROR_NONE && k.lg_chi == FLT_MAX && k.reached == 0)
                          ? kStaleIterations
                          : k.reached;
       r.errorCode = k.error;
@@ -2210,6 +2211,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
   const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz, one clock for the whole device
   const unsigned long long tr_c0 = __builtin_amdgcn_s_memtime();
   unsigned long long tr_eval = 0, tr_steps = 0, tr_solve = 0, tr_fetch = 0, tr_post = 0;
+  unsigned long long tr_idle = 0, tr_sleeps = 0; // SEQ: lane groups without work summed over the steps; all-waiting rounds
 #endif
   for (;;) {
     bool may_fetch = true;
@@ -2417,11 +2419,17 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
             return;
           }
         }
+#ifdef LK_TRACE
+        ++tr_sleeps;
+#endif
         __builtin_amdgcn_s_sleep(16);
         continue;
       }
       if (waiting != ~0ull)
         wait_spins = 0;
+#ifdef LK_TRACE
+      tr_idle += (unsigned long long)(__builtin_popcountll(~__ballot(active)) / GROUP);
+#endif
     }
     if constexpr (GROUP >= kWave) {
       if (!active) {
@@ -2810,8 +2818,8 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
       w[4] = tr_fetch;
       w[5] = tr_post;
 #else
-      w[4] = hw;
-      w[5] = xcc;
+      w[4] = SEQ ? tr_idle : hw;
+      w[5] = SEQ ? tr_sleeps : xcc;
 #endif
       w[6] = __builtin_amdgcn_s_memtime() - tr_c0; // shader cycles of the whole wavefront
       w[7] = tr_solve; // cycles inside damped_step
@@ -4125,9 +4133,9 @@ hipError_t lk_launch_solve(const LkSolveArgs &a, int model, int interp, int grou
 }
 
 // ---- frame-pipelined launches (the SEQ instances) --------------------------------------------------------------
-// One persistent grid per size class for a whole window of frames.  No more groups than the class has sectors (a group
-// beyond that could only wait for a sector's previous frame), no more wavefronts than are resident (more would not
-// hurt - a wavefront that is not running holds no ticket - but would queue behind the grid for nothing).
+// One persistent grid per size class for a whole window of frames: a share of the class's sector count (below), and no more
+// wavefronts than are resident (more would not hurt - a wavefront that is not running holds no ticket - but would queue
+// behind the grid for nothing).
 template <int MODEL, int INTERP, int GROUP, bool SAFE, bool REF>
 static hipError_t launch_solve_seq_gs(const LkSolveArgs &a, hipStream_t st) {
   static std::atomic<int> resident_cache{0};
@@ -4137,14 +4145,26 @@ static hipError_t launch_solve_seq_gs(const LkSolveArgs &a, hipStream_t st) {
     resident_cache.store(resident, std::memory_order_relaxed);
   }
   const int per_wg = kWave / GROUP;
-  const int want = (a.n_sectors + per_wg - 1) / per_wg;
   LkSolveArgs b = a;
   b.persistent = 1;
   b.chunk = 0;
   b.team_w = 0;
   b.solo = 0;
-  int grid = want < resident ? want : resident;
-  static const int grid_permille = [] { // tuning hook: the grid as a share of min(sectors / groups per wavefront, resident)
+  // A sector has at most one frame in work at a time, so groups beyond the sectors could only wait; and with nearly as many
+  // groups as sectors a group that is done draws the next frame of a sector whose current frame is still being solved by a
+  // slower group, and waits.  Measured on config 2 (10 000 sectors, 32-lane groups, 4096 resident wavefronts): 8192 groups
+  // 0.166 ms per pair, 6144 groups 0.160, 4096 groups 0.201; config 4 (50 176 sectors, 12 288 resident groups) wants them all.
+  // The reference-order rows are different: their lanes are dealt by need, a waiting row's lanes work for the wavefront's
+  // other sectors, and the kernel is bound by the latency of its QR chains - it wants every resident wavefront it can get
+  // (config 2: 1875 / 2500 / 3072 wavefronts 0.361 / 0.342 / 0.332 ms per pair).
+  static const int fill_env = [] { // tuning hook: groups per 1000 sectors at most
+    const char *f = getenv("LK_SEQ_FILL");
+    return f ? atoi(f) : 0;
+  }();
+  const int fill_permille = fill_env > 0 ? fill_env : (REF && GROUP == 16 ? 1250 : 640);
+  const int fill = (int)(((long long)a.n_sectors * fill_permille / 1000 + per_wg - 1) / per_wg);
+  int grid = fill < resident ? fill : resident;
+  static const int grid_permille = [] { // tuning hook: the grid as a share of that
     const char *f = getenv("LK_SEQ_GRID");
     return f ? atoi(f) : 1000;
   }();

@@ -931,6 +931,113 @@ int lk_sequence_run(lk_engine *e, lk_tracker *t, int n_frames, lk_frame_provider
     rc = lk_tracker_begin_frame(t, 0, cmds.data(), guesses.data());
     if (!rc)
       rc = register_sectors(e, t, cmds);
+    // Windows of K pairs (LK_SEQ_WINDOW, default 32; 1 = pair by pair, below): the K deformed frames of a window are
+    // resident in the engine's ring and ONE launch per size class solves them all, every sector moving on to its next
+    // frame as soon as its own previous frame is done (lk_correlate_sequence_async) - the guess of pair k + 1 needs
+    // nothing but the sector's own earlier results (manager_class.cpp:2677-2699).  While window w is being solved a helper
+    // thread fetches and uploads the frames of window w + 1 into the other half of the ring (:1438-1447, K frames ahead
+    // instead of one), and the tracker's bookkeeping of window w - 1 (update_results, global results, report rows) runs
+    // on this thread.  Same records, same report text as the pair-by-pair loop in batch-invariant and reference-order
+    // mode (tests/test_sequence_window_gpu.py).
+    const char *win_env = std::getenv("LK_SEQ_WINDOW");
+    const int K = std::min(pairs, win_env ? std::max(1, std::atoi(win_env)) : 32);
+    if (!rc && K >= 2) {
+      const int R = 2 * K;
+      rc = lk_sequence_reserve(e, R);
+      std::vector<std::string> frame_name((size_t)n_frames);
+      frame_name[0] = f0.name;
+      frame_name[1] = f1.name;
+      if (!rc)
+        rc = lk_sequence_set_frame(e, 0, f1.px, f1.rows, f1.cols, f1.step);
+      auto upload = [&](int f) -> int { // frame f (f >= 1) -> ring slot (f - 1) % R
+        Frame fr = fetch(f);
+        if (!fr.px)
+          return (int)LK_ERROR_BAD_DOMAIN;
+        frame_name[(size_t)f] = fr.name;
+        return lk_sequence_set_frame(e, (f - 1) % R, fr.px, fr.rows, fr.cols, fr.step);
+      };
+      for (int f = 2; f <= K && !rc; ++f)
+        rc = upload(f);
+      std::vector<lk_result> win[2];
+      std::vector<float> win_guess[2], win_first[2]; // check mode: the guesses the device solved from (first frame: the guess kernel's)
+      win[0].resize((size_t)K * (size_t)S);
+      win[1].resize((size_t)K * (size_t)S);
+      if (check)
+        for (int b = 0; b < 2; ++b) {
+          win_guess[b].resize((size_t)K * 6 * (size_t)S);
+          win_first[b].resize(6 * (size_t)S);
+        }
+      std::future<int> next;
+      int have_first = -1, have_n = 0, have_buf = 0; // a solved window whose bookkeeping is still to be done
+      auto bookkeeping = [&]() -> int {
+        int r = LK_ERROR_NONE;
+        for (int i = 0; i < have_n && !r; ++i) {
+          const int k = have_first + i;
+          const std::string &und_k = t->cfg.reference_image == LK_REF_PREVIOUS ? frame_name[(size_t)k] : frame_name[0];
+          if (k > 0) // (frame 0's begin_frame ran before the sectors were registered; its guesses are still in `guesses`)
+            r = lk_tracker_begin_frame(t, k, cmds.data(), guesses.data());
+          if (!r && check) {
+            const float *dev = i > 0 ? win_guess[have_buf].data() + (size_t)i * 6 * (size_t)S : win_first[have_buf].data();
+            if (std::memcmp(dev, guesses.data(), 6 * (size_t)S * sizeof(float)) != 0)
+              r = t->fail(LK_ERROR_BAD_DOMAIN, "lk_sequence_run: device guesses differ from the tracker's");
+          }
+          int first_unsolved = S, stop = 0; // (never a stop: the continue policy is a condition of this path)
+          if (!r)
+            r = lk_tracker_end_frame(t, k, und_k.c_str(), frame_name[(size_t)k + 1].c_str(), win[have_buf].data() + (size_t)i * (size_t)S,
+                                     &first_unsolved, &stop);
+          if (!r && pairs_done)
+            *pairs_done = k + 1;
+        }
+        have_n = 0;
+        return r;
+      };
+      for (int first = 0, w = 0; first < pairs && !rc; first += K, ++w) {
+        const int n = std::min(K, pairs - first), buf = w & 1;
+        if (next.valid()) { // this window's frames (uploaded behind the previous window's solve)
+          const int nrc = next.get();
+          if (nrc) // error_multiThread in the reference (manager_class.cpp:1470-1475)
+            rc = nrc;
+        }
+        if (!rc)
+          rc = lk_adjust_initial_guess(e, first, velocity ? 1 : 0, gg, t->x_center, t->y_center);
+        if (!rc && check)
+          rc = lk_get_guesses(e, win_first[buf].data());
+        bool launched = false;
+        if (!rc) {
+          rc = lk_correlate_sequence_async(e, (t->cfg.reference_image == LK_REF_PREVIOUS && first > 0) ? (first - 1) % R : -1, first % R, n,
+                                           t->cfg.reference_image == LK_REF_PREVIOUS ? 1 : 0, velocity ? 1 : 0, check ? 3 : 1);
+          launched = !rc;
+        }
+        if (!rc && first + K < pairs) {
+          const int f_begin = first + K + 1, f_end = std::min(first + 2 * K, pairs);
+          next = std::async(std::launch::async, [&, f_begin, f_end] {
+            int r = LK_ERROR_NONE;
+            for (int f = f_begin; f <= f_end && !r; ++f)
+              r = upload(f);
+            return r;
+          });
+        }
+        if (!rc && have_n > 0) // the window before: its bookkeeping runs behind the solve just launched
+          rc = bookkeeping();
+        if (launched) {
+          const int wrc = lk_wait_sequence(e, rc ? nullptr : win[buf].data());
+          if (!rc)
+            rc = wrc;
+        }
+        if (!rc && check)
+          rc = lk_get_sequence_guesses(e, win_guess[buf].data());
+        if (!rc) {
+          have_first = first;
+          have_n = n;
+          have_buf = buf;
+        }
+      }
+      if (next.valid())
+        (void)next.get();
+      if (!rc && have_n > 0)
+        rc = bookkeeping();
+      return rc;
+    }
     if (!rc)
       rc = launch(0);
     if (!rc && !verify())

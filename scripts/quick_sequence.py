@@ -56,7 +56,8 @@ for r in range(reps + 1):
         ms_ev.append(e.stats()["solve_ms"])
 st = e.stats()
 pipelined = e.sequence_is_pipelined
-e.correlate_sequence_async(n, constant_velocity=True, host_records=True)   # (same guesses of frame 0: d_guess is untouched)
+e.adjust_initial_guess(0, True, ZERO, c)
+e.correlate_sequence_async(n, constant_velocity=True, host_records=True)
 rec = e.wait_sequence()
 ms = float(np.median(ms_ev))
 print(f"{wl.name}\n mode {mode}, window of {n} frames, pipelined {pipelined}: {ms / n:.4f} ms per pair (events; wall {np.median(ms_wall) / n:.4f})"
@@ -75,7 +76,6 @@ if os.environ.get("LK_SEQ_LOOP", "1") != "0":
         a.adjust_initial_guess(k, True, ZERO, c)
         a.correlate_all_async()
         got = a.wait_results()
-        ev_loop.append(a.stats()["solve_ms"]) if False else None
         same += got.tobytes() == rec[k].tobytes()
         if k + 1 < n:
             a.makeDefPyramidFromNxt()

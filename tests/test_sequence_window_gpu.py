@@ -209,8 +209,10 @@ def test_64_frame_sequences_at_full_size(wl, mode):
         a.adjust_initial_guess(k, True, ZERO, c)
         want = a.correlate_all(None)
         assert got[k].tobytes() == want.tobytes(), f"frame {k}"
+    # (the image content moves by 0.8 n px: the sectors within that distance of the right edge lose it - out of image; config
+    # 4's 7 x 7-sample sectors also run into max_iters on their singular levels, in the reference as here)
     ok = got["error_code"][-1] == 0
-    assert ok.mean() > 0.99
+    assert (got["error_code"][0] == 0).mean() > 0.99 and ok.mean() > (0.9 if wl is C2 else 0.7)
     u = 0.8 * n + 1e-4 * n * (got["und_cx"][-1] - 1024.0)
     assert np.median(np.abs(got["p"][-1][:, 0] - u)[ok]) < 0.05
     a.close()
