@@ -41,7 +41,7 @@ N_SIMDS, PEAK_CLOCK_HZ, VALU_ISSUE_CYCLES = 1024, 2.4e9, 2.0   # 256 CUs x 4 SIM
 def profile_constants():
     """Per-launch constants of the C2 solve kernels from the committed rocprofv3 --pmc passes (profiles/): HBM bytes
     (FETCH_SIZE + WRITE_SIZE) and VALU wavefront-instructions (SQ_INSTS_VALU).  NOT counters read in this run."""
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:
@@ -54,11 +54,19 @@ def profile_constants():
     return {}
 
 
-def valu_issue_frac(valu_insts, kernel_ms):
-    """Share of the chip's VALU issue slots the launch used: instructions x 2 cycles / (1024 SIMDs x 2.4 GHz x time)."""
+def valu_issue_frac(valu_insts, kernel_ms, clock_hz=PEAK_CLOCK_HZ):
+    """Share of the chip's VALU issue slots the launch used: instructions x 2 cycles / (1024 SIMDs x clock x time).
+    The 2 cycles per wave64 f32 instruction are an assumption the frame-pipelined windows bound from above: config 2's
+    window sustains 0.65 of that rate over 10 ms (profiles/r04_seq_pmc.txt), so an instruction costs a SIMD < 3.1 cycles."""
     if not valu_insts or not kernel_ms:
         return None
-    return valu_insts * VALU_ISSUE_CYCLES / (N_SIMDS * PEAK_CLOCK_HZ * kernel_ms * 1e-3)
+    return valu_insts * VALU_ISSUE_CYCLES / (N_SIMDS * clock_hz * kernel_ms * 1e-3)
+
+
+def measured_clock_hz(key):
+    """shader clock the traced wavefronts of that launch actually ran at (profiles/*_wave_timeline.txt), or None"""
+    g = profile_constants().get("measured_clock_GHz", {}).get(key)
+    return g * 1e9 if g else None
 
 
 def cpu_baseline(wl, und, dfm, budget_sectors):
@@ -304,9 +312,15 @@ def sequence_block(ca, torch, dev, wl, d_frames, mode, repeats=3, check_loop=Tru
                       "evaluations_per_sector_and_pair": st["evaluations"] / st["sectors"],
                       "error_free_fraction_first_pair": float((rec[0]["error_code"] == 0).mean()),
                       "error_free_fraction_last_pair": float((rec[-1]["error_code"] == 0).mean())}}
-    vk = profile_constants().get("valu_insts_per_window_pair", {}).get(f"{wl.name.split(':')[0]}_{mode}")
+    key = f"{wl.name.split(':')[0]}_{mode}"
+    vk = profile_constants().get("valu_insts_per_window_pair", {}).get(key)
     if vk:
         out["window"]["valu_issue_frac"] = valu_issue_frac(vk, kms)
+        clk = measured_clock_hz(f"window_{key}")
+        if clk:
+            out["window"]["valu_issue_frac_at_measured_clock"] = valu_issue_frac(vk, kms, clk)
+            out["window"]["measured_clock_GHz"] = clk / 1e9
+        out["window"]["traffic_hbm_bytes_per_pair"] = profile_constants().get("hbm_bytes_per_window_pair", {}).get(key)
     if check_loop:
         a = engine()
         a.set_timing(False)
@@ -894,7 +908,12 @@ def main():
                                     "lk_solve_kernel<fm_UVUxUyVxVy, im_bicubic>: all launches of one solve"),
                          "kernel_ms": solve_avg_ms,
                          "valu_issue_frac": valu_frac,
-                         "valu_issue_frac_is": "SQ_INSTS_VALU per launch (profile constant) x 2 cycles / (1024 SIMDs x 2.4 GHz x kernel_ms): "
+                         "valu_issue_frac_at_measured_clock": (valu_issue_frac(profile_constants().get("solve_kernel_valu_insts_per_launch_C2"), solve_avg_ms,
+                                                                               measured_clock_hz("one_pair_C2"))
+                                                               if (not strong and measured_clock_hz("one_pair_C2")) else None),
+                         "measured_clock_GHz": (measured_clock_hz("one_pair_C2") or 0) / 1e9 or None,
+                         "valu_issue_frac_is": "SQ_INSTS_VALU per launch (profile constant) x 2 cycles / (1024 SIMDs x 2.4 GHz x kernel_ms) - beside it the same at the clock the traced "
+                                               "wavefronts ran at (profiles/r03_wave_timeline.txt): "
                                                "the binding limit of this kernel is VALU issue and the critical path of its slowest sectors, not HBM",
                          "measured": "K back-to-back solve launches of the engine and stream the timed region ran on, "
                                      "between two HIP events on that stream",

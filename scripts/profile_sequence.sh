@@ -1,0 +1,35 @@
+#!/bin/bash
+# Evidence of the frame-pipelined windows for profiles/ (run through gpurun from the repo root): scripts/profile_sequence.sh r04
+#  1. rocprofv3 --kernel-trace --stats of scripts/quick_sequence.py (window + the one-pair loop of the same sequence)
+#     -> <tag>_seq_<WL>_kernel_stats.csv
+#  2. separate --pmc passes over the window alone -> <tag>_seq_pmc.txt, <tag>_seq_traffic.json (VALU instructions and HBM
+#     bytes per pair of a window: bench.py's sequence.*.window.valu_issue_frac)
+#  3. build/tune/liblk_trace_seq*.so present: the per-wavefront account of one window -> <tag>_seq_wave_timeline.txt
+set -uo pipefail
+tag=${1:-r04}
+out=gpurun_out/prof_$tag
+mkdir -p "$out"
+export TMPDIR=/tmp
+for wl in C2 C4; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/seqtrace_$wl" -o t -- python3 scripts/quick_sequence.py $wl 64 3 > "$out/${tag}_seq_${wl}.log" 2>&1
+  find "$out/seqtrace_$wl" -name '*kernel_stats.csv' -exec cp {} "$out/${tag}_seq_${wl}_kernel_stats.csv" \;
+  rm -rf "$out/seqtrace_$wl"
+  echo "trace $wl done" >> "$out/progress.log"
+done
+: > "$out/${tag}_seq_pmc.txt"
+for cfg in "C2 default" "C2 reference_order" "C4 default" "C4 batch_invariant"; do
+  set -- $cfg
+  i=0
+  for set in "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i + 1))
+    LK_MODE=$2 LK_SEQ_LOOP=0 timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d "$out/pmc$i" -o pmc -- python3 scripts/quick_sequence.py $1 64 1 > "$out/spmc.log" 2>&1 || echo "pass $i ($set) of $cfg failed" >> "$out/progress.log"
+  done
+  python3 scripts/summarize_pmc.py "$out" "$tag: window of 64 pairs, $1, LK_MODE=$2 (scripts/quick_sequence.py $1 64 1: three launches of the window kernel)" | grep -v "^units\|lk_pyramid\|lk_guess\|lk_set_views\|lk_stale" >> "$out/${tag}_seq_pmc.txt"
+  rm -rf "$out"/pmc*/
+  echo "pmc $cfg done" >> "$out/progress.log"
+done
+for lib in build/tune/liblk_trace_seq32.so:C2:default build/tune/liblk_trace_seq16.so:C4:default build/tune/liblk_trace_seq16.so:C2:reference_order; do
+  IFS=: read -r so wl mode <<< "$lib"
+  [ -f "$so" ] && LK_MODE=$mode LK_ENGINE_LIB=$PWD/$so timeout -k 10 200 python3 scripts/trace_sequence.py $wl 64 2>&1 | grep -v amdgpu.ids >> "$out/${tag}_seq_wave_timeline.txt" && echo >> "$out/${tag}_seq_wave_timeline.txt"
+done
+cat "$out/${tag}_seq_pmc.txt"; cat "$out/${tag}_seq_wave_timeline.txt"
