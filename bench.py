@@ -430,12 +430,39 @@ def sharded_config(ca, torch, dist, wl, rank, world, local_rank, steps, warmup):
         if use_dist:
             dist.all_gather_into_tensor(d_all.view(-1, 48), d_rec)
 
-    ms1 = timed(one_gpu, steps)
-    full.set_timing(True)
-    one_gpu()
-    torch.cuda.synchronize(dev)
-    st1 = full.stats()
-    ms = timed(sharded, steps)
+    ok, err = 1, None
+    ms1 = ms = None
+    st1 = {"point_iterations": 0}
+    try:
+        ms1 = timed(one_gpu, steps)
+        full.set_timing(True)
+        one_gpu()
+        torch.cuda.synchronize(dev)
+        st1 = full.stats()
+    except Exception as ex:   # noqa: BLE001
+        ok, err = 0, repr(ex)
+    if use_dist:   # (a rank that failed alone must not leave the others in the collectives of the sharded run)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok_all = int(flag.item())
+    else:
+        ok_all = ok
+    if ok_all:
+        try:
+            ms = timed(sharded, steps)
+        except Exception as ex:   # noqa: BLE001
+            ok, err = 0, repr(ex)
+        if use_dist:
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok_all = int(flag.item())
+        else:
+            ok_all = ok
+    if not ok_all:
+        for e in {id(x): x for x in (full, shard)}.values():
+            e.close()
+        info["error"] = err or "the timed region failed on another rank"
+        return info
     info.update({"ms_per_step": ms, "ms_per_step_1gpu": ms1, "speedup_vs_1gpu": ms1 / ms,
                  "point_iterations_per_s": st1["point_iterations"] / (ms * 1e-3),
                  "point_iterations_per_s_1gpu": st1["point_iterations"] / (ms1 * 1e-3),
@@ -443,6 +470,130 @@ def sharded_config(ca, torch, dist, wl, rank, world, local_rank, steps, warmup):
                  "step": "broadcast of the deformed frame + both pyramids + solve of the rank's block + all-gather of records"
                          if use_dist else "both pyramids + solve of the whole grid (one rank: no collectives)"})
     for e in {id(x): x for x in (full, shard)}.values():
+        e.close()
+    return info
+
+
+def sharded_sequence(ca, torch, dist, wl, d_frames, rank, world, local_rank, K=16):
+    """A tracked sequence with the sector grid split over the ranks in contiguous blocks (BASELINE config 4's
+    shape): every rank keeps the undeformed pyramid (built ONCE) and its block's guess history; per window of K pairs ONE
+    broadcast of the K new frames from rank 0 - issued before the window it overlaps is launched, into the other half of a
+    double buffer - every rank solves the window for its block (frame-pipelined instances), ONE all-gather of K x block
+    records.  Beside it the whole grid on one GPU (every rank on its own device, no collectives).  Every rank must call this;
+    failures are agreed on before and after the timed regions."""
+    from correlation_amd.workload import shard_range
+    use_dist = dist is not None
+    dev = torch.device("cuda", local_rank)
+    n = int(d_frames.shape[0]) - 1
+    size = int(d_frames.shape[1])
+    K = min(K, n)
+    c, zero = (size / 2 - 0.5, size / 2 - 0.5), np.zeros(6, np.float32)
+    info = {"workload": wl.name, "n_ranks": dist.get_world_size() if use_dist else 1, "sectors_total": wl.hs * wl.vs, "pairs": n,
+            "window_pairs": K, "scaling": "strong"}
+
+    def agree(ok):
+        if not use_dist:
+            return ok
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    full = shard = None
+    err = None
+    try:
+        def engine(first, count):
+            e = ca.HipCorrelationEngine(interpolation=ca.IM_BICUBIC, fitting_model=wl.model, py_stop=wl.py_stop, device=local_rank)
+            e.set_rect_grid(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, wl.hs, wl.vs, first, count)
+            e.commit_sectors()
+            e.sequence_reserve(2 * K)
+            return e
+        first, count = shard_range(wl.hs * wl.vs, rank, world)
+        shard = engine(first, count)
+        full = engine(0, wl.hs * wl.vs) if world > 1 else shard
+        cap = (wl.hs * wl.vs + world - 1) // world
+        stage = [torch.empty((K, size, size), dtype=torch.uint8, device=dev) for _ in range(2)]     # frames of a window, as they arrive
+        d_block = torch.zeros((K, cap, 48), dtype=torch.uint8, device=dev)
+        d_all = torch.empty((world, K, cap, 48), dtype=torch.uint8, device=dev) if use_dist else None
+        comm = torch.cuda.Stream(dev)
+    except Exception as ex:   # noqa: BLE001
+        err = repr(ex)
+    if not agree(err is None):
+        for e in {id(x): x for x in (full, shard) if x is not None}.values():
+            e.close()
+        info["error"] = err or "set-up failed on another rank"
+        return info
+
+    def fetch_window(w, buf, sharded):
+        """frames of window w -> stage[buf]: rank 0's, broadcast (sharded run), or the rank's own copy of the sequence"""
+        lo = 1 + w * K
+        k = min(K, n - w * K)
+        with torch.cuda.stream(comm):
+            if rank == 0 or not sharded:
+                stage[buf][:k].copy_(d_frames[lo:lo + k], non_blocking=True)
+            return dist.broadcast(stage[buf], src=0, async_op=True) if (use_dist and sharded) else None
+
+    def run(e, sharded):
+        """the whole sequence once; returns wall ms"""
+        n_win = (n + K - 1) // K
+        torch.cuda.synchronize(dev)
+        if use_dist and sharded:
+            dist.barrier()
+        t0 = time.perf_counter()
+        e.set_image_device(ca.IMG_UND, d_frames[0].data_ptr(), size, size)      # the undeformed pyramid: once per sequence
+        h = fetch_window(0, 0, sharded)
+        gather = None
+        for w in range(n_win):
+            k = min(K, n - w * K)
+            if h is not None:
+                h.wait()
+            comm.synchronize()                                                   # the frames of window w have arrived
+            for i in range(k):
+                e.sequence_set_frame_device((w % 2) * K + i, stage[w % 2][i].data_ptr(), size, size)
+            if w + 1 < n_win:
+                h = fetch_window(w + 1, (w + 1) % 2, sharded)                    # travels while window w is solved
+            e.adjust_initial_guess(w * K, True, zero, c)
+            e.correlate_sequence_async(k, first_slot=(w % 2) * K, constant_velocity=True, host_records=False)
+            e.wait_sequence(False)
+            if use_dist and sharded:
+                if gather is not None:
+                    gather.wait()                                                # (the previous all-gather has read d_block)
+                e.copy_sequence_records_device(d_block.data_ptr(), cap)          # [k][S_me] -> the padded block [K][cap], engine's stream
+                e.synchronize()
+                with torch.cuda.stream(comm):
+                    gather = dist.all_gather_into_tensor(d_all.view(-1, 48), d_block.view(-1, 48), async_op=True)
+        if gather is not None:
+            gather.wait()
+        comm.synchronize()
+        e.synchronize()
+        if use_dist and sharded:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) * 1e3
+
+    ok, err = True, None
+    ms_sharded = ms_one = None
+    try:
+        run(shard, True)                     # warm-up (allocations, first launches)
+        ms_sharded = run(shard, True)
+        if world > 1:
+            run(full, False)
+            ms_one = run(full, False)
+        else:
+            ms_one = ms_sharded
+    except Exception as ex:   # noqa: BLE001
+        ok, err = False, repr(ex)
+    if not agree(ok):
+        info["error"] = err or "the timed region failed on another rank"
+    else:
+        t = torch.tensor([ms_sharded, ms_one], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms_sharded, ms_one = float(t[0].item()), float(t[1].item())
+        info.update({"ms_per_pair": ms_sharded / n, "ms_per_pair_1gpu": ms_one / n, "speedup_vs_1gpu": ms_one / ms_sharded,
+                     "sectors_per_rank": int(shard.n_sectors),
+                     "step": "per window: one broadcast of its frames (behind the window before), pyramids, the frame-pipelined solve of "
+                             "the rank's block, one all-gather of its records; the undeformed pyramid once per sequence"})
+    for e in {id(x): x for x in (full, shard) if x is not None}.values():
         e.close()
     return info
 
@@ -823,10 +974,17 @@ def main():
 
     # ---- tracked sequences: configs 2 and 4 as 64-pair sequences, frame-pipelined window against the one-pair loop ----
     sequence = None
+    d_frames = None
+    if not strong and args.sequence_frames > 1:
+        try:
+            d_frames = sequence_frames(ca, torch, dev, C2.size, args.sequence_frames)
+        except Exception:   # noqa: BLE001 (the blocks that need them say so)
+            d_frames = None
     if world == 1 and not use_dist and not strong and args.sequence_frames > 1:
         sequence = {}
         try:
-            d_frames = sequence_frames(ca, torch, dev, C2.size, args.sequence_frames)
+            if d_frames is None:
+                raise RuntimeError("the synthetic sequence could not be rendered")
             for key, w_ in (("C2", C2), ("C4", C4)):
                 sequence[key] = {}
                 for mode in ("default", "reference_order"):
@@ -834,7 +992,6 @@ def main():
                         sequence[key][mode] = sequence_block(ca, torch, dev, w_, d_frames, mode)
                     except Exception as ex:   # noqa: BLE001 - extra evidence must never take the headline line down
                         sequence[key][mode] = {"error": repr(ex)}
-            del d_frames
         except Exception as ex:   # noqa: BLE001
             sequence["error"] = repr(ex)
         torch.cuda.set_stream(stream)
@@ -848,13 +1005,29 @@ def main():
                                               max(5, args.steps // 10), max(2, args.warmup // 10))
             except Exception as ex:   # noqa: BLE001 (a failure after the ranks agreed: reported, the headline stands)
                 sharded[key] = {"error": repr(ex)}
+        # ... and tracked SEQUENCES sharded the same way (frame-pipelined windows; the case in which one node's GPUs scale)
+        ok_frames = 1 if d_frames is not None else 0
+        if use_dist:
+            flag = torch.tensor([ok_frames], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok_frames = int(flag.item())
+        for key, w_ in (("C4_sequence", C4), ("C2_sequence", C2)):
+            if not ok_frames:
+                sharded[key] = {"error": "the synthetic sequence could not be rendered on every rank"}
+                continue
+            try:
+                sharded[key] = sharded_sequence(ca, torch, dist if use_dist else None, w_, d_frames, rank, world, local_rank)
+            except Exception as ex:   # noqa: BLE001
+                sharded[key] = {"error": repr(ex)}
+        torch.cuda.set_stream(stream)
+    d_frames = None
     native = None
     if not strong and not args.no_native_group:
         # the C-ABI group (one process, all devices) runs as a child of rank 0 while the other ranks keep off the GPUs:
         # a host-only rendezvous through a file, bounded waits on both sides
         flag_path = None
         if use_dist:
-            tok = torch.tensor([int(time.time() * 1e3) % (1 << 30) if rank == 0 else 0], dtype=torch.int64, device=dev)
+            tok = torch.tensor([int.from_bytes(os.urandom(6), "little") if rank == 0 else 0], dtype=torch.int64, device=dev)   # (not guessable)
             dist.broadcast(tok, src=0)
             torch.cuda.synchronize(dev)
             flag_path = os.path.join("/tmp", f"lk_bench_native_{int(tok.item())}.done")
@@ -867,6 +1040,8 @@ def main():
             t_wait = time.time()
             while not os.path.exists(flag_path) and time.time() - t_wait < 300:
                 time.sleep(0.2)
+            if not os.path.exists(flag_path):
+                sys.stderr.write(f"rank {rank}: the native-group child of rank 0 did not finish within 300 s\n")
 
     if rank == 0:
         value = total_pit / dt_max

@@ -101,6 +101,7 @@ SYMBOLS = {
     "lk_wait_sequence": (C.c_int, [_P, _P]),
     "lk_get_sequence_results_device": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "lk_sequence_is_pipelined": (C.c_int, [_P]),
+    "lk_copy_sequence_records_device": (C.c_int, [_P, _P, C.c_size_t]),
     "lk_get_sequence_guesses": (C.c_int, [_P, _F]),
     "lk_adjust_initial_guess": (C.c_int, [_P, C.c_int, C.c_int, _F, C.c_float, C.c_float]),
     "lk_get_guesses": (C.c_int, [_P, _F]),
@@ -154,6 +155,13 @@ SYMBOLS = {
     "lk_group_sector_count": (C.c_int, [_P]),
     "lk_group_correlate_all": (C.c_int, [_P, _F, _P]),
     "lk_group_adjust_initial_guess": (C.c_int, [_P, C.c_int, C.c_int, _F, C.c_float, C.c_float]),
+    "lk_group_sequence_reserve": (C.c_int, [_P, C.c_int]),
+    "lk_group_sequence_set_frames": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
+    "lk_group_sequence_set_frames_device": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
+    "lk_group_correlate_sequence_async": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "lk_group_wait_sequence": (C.c_int, [_P, _P]),
+    "lk_group_sequence_records_device": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "lk_group_probe_overlap": (C.c_int, [_P, C.c_int, _F]),
     "lk_group_records_device": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
     "lk_group_block_records": (C.c_int, [_P]),
     "lk_group_synchronize": (C.c_int, [_P]),

@@ -589,8 +589,10 @@ static int fill_image(lk_engine *e, DevImage &im, const void *src, bool src_on_d
   return LK_ERROR_NONE;
 }
 
+// after / consumed (lk_group: frames that arrive by a collective on another stream): the fill waits for `after` on its
+// stream instead of the host waiting for the collective, and `consumed` is recorded behind the last kernel that reads src
 static int set_image_common(lk_engine *e, int slot, const void *src, bool src_on_device, int rows,
-                            int cols, int step) {
+                            int cols, int step, hipEvent_t after = nullptr, hipEvent_t consumed = nullptr) {
   Range range_("lk:upload+pyramid");
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
@@ -606,11 +608,15 @@ static int set_image_common(lk_engine *e, int slot, const void *src, bool src_on
     st = e->nxt_stream;
   }
   DevImage &im = e->img[slot];
+  if (after)
+    HIPCHK(hipStreamWaitEvent(st, after, 0));
   {
     int rc = fill_image(e, im, src, src_on_device, rows, cols, step, st, slot != LK_IMG_NXT && e->timing);
     if (rc)
       return rc;
   }
+  if (consumed)
+    HIPCHK(hipEventRecord(consumed, st));
   if (slot == LK_IMG_NXT) {
     HIPCHK(hipEventRecord(e->nxt_done, st));
     e->nxt_pending = true;
@@ -2545,6 +2551,20 @@ int lk_internal_set_defer_stale(lk_engine *e, int on) { // (lk_internal.hpp)
   return LK_ERROR_NONE;
 }
 int lk_internal_reference_order(const lk_engine *e) { return e ? e->reference_order : 0; }
+int lk_internal_set_image_device_after(lk_engine *e, int slot, const void *device_pixels, int rows, int cols, int step,
+                                       hipEvent_t after, hipEvent_t consumed) {
+  return set_image_common(e, slot, device_pixels, true, rows, cols, step, after, consumed);
+}
+// does a solve of this engine launch teams (workgroups that wait for each other and must all be resident)?  A collective
+// kernel on another stream could hold the slots one of them needs: the group then keeps its collectives in stream order.
+int lk_internal_team_launches(const lk_engine *e) {
+  if (!e || !e->committed)
+    return 0;
+  const int n_team = e->class_begin[kTeamClass + 1] - e->class_begin[kTeamClass];
+  const int n_big = e->class_begin[kTeamClass + 1] - e->class_begin[kTeamClass - 1];
+  return (n_team > 0 && e->team_w > 1) || (e->reference_order > 1 && n_big > 0) ? 1 : 0;
+}
+int lk_internal_sector_count(const lk_engine *e) { return e ? e->S : 0; }
 
 extern "C" {
 
@@ -2728,7 +2748,8 @@ int lk_sequence_reserve(lk_engine *e, int n_slots) {
   return LK_ERROR_NONE;
 }
 
-static int sequence_set_frame(lk_engine *e, int slot, const void *src, bool on_device, int rows, int cols, int step) {
+static int sequence_set_frame(lk_engine *e, int slot, const void *src, bool on_device, int rows, int cols, int step,
+                              hipEvent_t after = nullptr, hipEvent_t consumed = nullptr) {
   Range range_("lk:upload+pyramid (ring)");
   if (!e)
     return LK_ERROR_BAD_DOMAIN;
@@ -2743,9 +2764,13 @@ static int sequence_set_frame(lk_engine *e, int slot, const void *src, bool on_d
   hipStream_t st = e->nxt_stream;
   if (e->ring_window[(size_t)slot]) // a window read this slot: it must be through with it (stream order on the device)
     HIPCHK(hipStreamWaitEvent(st, e->seq_done[(e->ring_window[(size_t)slot] - 1) % 4], 0));
+  if (after)
+    HIPCHK(hipStreamWaitEvent(st, after, 0));
   int rc = fill_image(e, e->ring[(size_t)slot], src, on_device, rows, cols, step, st, false);
   if (rc)
     return rc;
+  if (consumed)
+    HIPCHK(hipEventRecord(consumed, st));
   HIPCHK(hipEventRecord(e->ring_ready[(size_t)slot], st));
   e->ring_fresh[(size_t)slot] = 1;
   lock.unlock();
@@ -2760,6 +2785,12 @@ int lk_sequence_set_frame(lk_engine *e, int slot, const uint8_t *host_pixels, in
 int lk_sequence_set_frame_device(lk_engine *e, int slot, const void *device_pixels, int rows, int cols, int step) {
   return sequence_set_frame(e, slot, device_pixels, true, rows, cols, step);
 }
+} // extern "C"
+int lk_internal_sequence_set_frame_device_after(lk_engine *e, int slot, const void *device_pixels, int rows, int cols, int step,
+                                                hipEvent_t after, hipEvent_t consumed) { // (lk_internal.hpp)
+  return sequence_set_frame(e, slot, device_pixels, true, rows, cols, step, after, consumed);
+}
+extern "C" {
 
 // lane group and flavour of a class inside a window (-1: the class has no frame-pipelined instance)
 static int seq_group_of_class(const lk_engine *e, int c, int n) {
@@ -3098,6 +3129,17 @@ int lk_get_sequence_results_device(lk_engine *e, const void **d_records, const v
 }
 
 int lk_sequence_is_pipelined(lk_engine *e) { return e && e->seq.pipelined ? 1 : 0; }
+
+int lk_copy_sequence_records_device(lk_engine *e, void *d_dst, size_t dst_pitch_records) {
+  if (!e || !d_dst)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!e->d_seq_result.p || e->seq.n_frames < 1 || dst_pitch_records < (size_t)e->S)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_copy_sequence_records_device: no window was solved, or the pitch is below the sector count");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipMemcpy2DAsync(d_dst, dst_pitch_records * sizeof(lk_result), e->d_seq_result.p, (size_t)e->S * sizeof(lk_result),
+                          (size_t)e->S * sizeof(lk_result), (size_t)e->seq.n_frames, hipMemcpyDeviceToDevice, e->stream));
+  return LK_ERROR_NONE;
+}
 
 int lk_get_sequence_guesses(lk_engine *e, float *out) {
   if (!e || !out)

@@ -10,6 +10,15 @@
 // one-GPU rehearsal mode (the same device listed several times), where device-to-device copies
 // and a host barrier stand in for the two collectives.
 //
+// Streams.  Every member has its solve stream (the engine's) and a COMMUNICATION stream: frame uploads, broadcasts,
+// all-gathers, the stale-count pass over gathered records and the copies of records to the host run there, ordered
+// against the solves by events - never by the host.  The broadcast of frame k + 1 therefore travels while pair k is
+// being solved (the reference's prefetch, manager_class.cpp:1438-1447, across GPUs), and the records of pair k leave
+// while pair k + 1 is being solved.  Buffers are protected the same way: a frame buffer is overwritten only after the
+// engine's pyramid kernel that read it (`consumed`), the padded record block only after the all-gather that read it.
+// An engine whose solves launch TEAMS (workgroups that wait for each other) keeps its collectives on the solve stream:
+// an RCCL kernel beside a team launch could hold a slot one of its workgroups needs.
+//
 // Failures.  A member that gave up before a collective would leave the others' collective - and rank 0's
 // hipStreamSynchronize behind it - waiting for ever.  So every job is cut into phases: what can fail on one
 // member alone (allocations, a deferred re-commit inside the engine, uploads, the solve launch) comes first, then
@@ -46,13 +55,33 @@ struct SectorSpec { // what lk_group_set_sector_* recorded, replayed on the owne
   std::vector<float> xy;
 };
 
+struct FrameBuf { // level-0 pixels of one image slot / ring slot on one member, dense rows
+  uint8_t *p = nullptr;
+  size_t cap = 0;
+  hipEvent_t arrived = nullptr;  // comm stream: the pixels are here
+  hipEvent_t consumed = nullptr; // engine's fill stream: the last kernel that reads them is done
+  hipEvent_t up = nullptr;       // rehearsal transport, rank 0: the upload is done
+  hipEvent_t copied = nullptr;   // rehearsal transport, other ranks: rank 0's pixels have been copied
+  bool consumed_valid = false, copied_valid = false;
+};
+
 struct Member {
   int rank = 0, device = 0;
   lk_engine *e = nullptr;
   hipStream_t st = nullptr;
+  hipStream_t cst = nullptr; // communication stream
   ncclComm_t comm = nullptr;
-  uint8_t *d_frame[3] = {nullptr, nullptr, nullptr}; // level-0 pixels of the slots, dense rows
-  size_t frame_cap[3] = {0, 0, 0};
+  FrameBuf frame[3];
+  std::vector<FrameBuf> ring;   // frame-pipelined windows: the resident deformed frames - slices of ONE allocation, so that the
+  uint8_t *d_ring = nullptr;    //   frames of a whole window travel in one broadcast
+  size_t ring_slot_bytes = 0;
+  hipEvent_t ev_solved = nullptr, ev_gathered = nullptr, ev_block = nullptr; // solve done (st) / records gathered (cst) / rehearsal: my block is in everybody's d_all
+  bool gathered_valid = false;
+  hipEvent_t probe[4] = {nullptr, nullptr, nullptr, nullptr}; // timing: last frame transfer begin / end (cst), last solve begin / end (st)
+  bool probe_valid[2] = {false, false};
+  lk_result *d_seq_rec = nullptr, *d_seq_all = nullptr; // windows: [frames][cap] of this member, [n][frames][cap] of everybody
+  size_t seq_frames_cap = 0;
+  int seq_frames = 0; // frames of the outstanding window (0: none)
   float *d_guess = nullptr;   // [cap][6]
   lk_result *d_rec = nullptr; // [cap] this member's block (padded)
   lk_result *d_all = nullptr; // [n][cap] everybody's blocks
@@ -70,6 +99,8 @@ struct lk_group {
   lk_config cfg{};
   std::vector<Member> m;
   bool loopback = false; // duplicate devices: copies + host barrier instead of RCCL (rehearsal on one GPU)
+  bool copy_frames = false; // frames by device-to-device copies from rank 0's buffer (copy engines over xGMI, no CU needed)
+                            // instead of ncclBroadcast: always in the rehearsal transport, LK_GROUP_FRAMES=copy otherwise
   // sector registry (global index)
   std::vector<SectorSpec> secs;
   bool grid = false;
@@ -209,18 +240,30 @@ void worker(lk_group *g, int rank) {
     }                                                                                                \
   } while (0)
 
-int ensure_frame(lk_group *g, Member &me, int slot, size_t bytes) {
-  if (me.frame_cap[slot] >= bytes)
+hipStream_t comm_stream(const Member &me) { return lk_internal_team_launches(me.e) ? me.st : me.cst; }
+
+int ensure_events(lk_group *g, Member &me, FrameBuf &fb) {
+  for (hipEvent_t *ev : {&fb.arrived, &fb.consumed, &fb.up, &fb.copied})
+    if (!*ev)
+      GHIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+  return LK_ERROR_NONE;
+}
+
+int ensure_frame(lk_group *g, Member &me, FrameBuf &fb, size_t bytes) {
+  if (int rc = ensure_events(g, me, fb))
+    return rc;
+  if (fb.cap >= bytes)
     return LK_ERROR_NONE;
-  // readers of the old buffer: the pyramid kernel of the previous frame (the next-frame slot's runs
-  // on the engine's own next-frame stream)
+  // readers / writers of the old buffer: the engine's fill (its own streams), the collectives (cst)
   GLK(lk_synchronize(me.e));
-  if (me.d_frame[slot])
-    GHIP(hipFree(me.d_frame[slot]));
-  me.d_frame[slot] = nullptr;
-  me.frame_cap[slot] = 0;
-  GHIP(hipMalloc((void **)&me.d_frame[slot], bytes));
-  me.frame_cap[slot] = bytes;
+  GHIP(hipStreamSynchronize(me.cst));
+  if (fb.p)
+    GHIP(hipFree(fb.p));
+  fb.p = nullptr;
+  fb.cap = 0;
+  fb.consumed_valid = fb.copied_valid = false;
+  GHIP(hipMalloc((void **)&fb.p, bytes));
+  fb.cap = bytes;
   return LK_ERROR_NONE;
 }
 
@@ -234,43 +277,83 @@ int collective_failed(lk_group *g, Member &me, int rc) {
   return rc;
 }
 
-// Pixels are (being copied) in rank 0's d_frame[slot] - `upload_rc` is what that member's upload returned -:
-// send them to everybody and build the pyramids.
-int distribute_frame(lk_group *g, Member &me, int slot, int rows, int cols, int upload_rc) {
+// n consecutive frames (one image slot: n = 1; ring slots first .. first + n - 1, contiguous in memory) to every member:
+// rank 0 uploads them into its buffer, the pixels travel in ONE transfer (ncclBroadcast; or device-to-device copies from
+// rank 0's buffer), every member's engine builds the pyramids.  All of it on the communication stream and the engine's
+// fill stream, ordered by events: the host returns when everything is ENQUEUED.
+// which(member, i): the member's FrameBuf of frame i; src(i): its pixels (host, or rank 0's device);
+// fill(member, i, buf): hands the pixels to the member's engine (image slot or ring slot).
+int distribute_frames(lk_group *g, Member &me, int n_frames, const std::function<FrameBuf &(Member &, int)> &which,
+                      const std::function<const void *(int)> &src, bool on_device0, int rows, int cols, int step,
+                      const std::function<int(Member &, int, FrameBuf &)> &fill) {
   const size_t bytes = (size_t)rows * (size_t)cols;
-  auto local = [&](int rc) { return me.device_ok ? rc : LK_ERROR_DEVICE; };
-  if (int rc = g->agree(local(upload_rc))) // nobody enters the collective unless every member got this far
-    return rc;
-  if (!g->loopback) {
+  FrameBuf &f0 = which(me, 0);
+  hipStream_t cs = comm_stream(me);
+  const bool by_copy = g->loopback || g->copy_frames;
+  int up = me.device_ok ? LK_ERROR_NONE : LK_ERROR_DEVICE;
+  auto hip = [&](hipError_t he, const char *what, int &rc) {
+    if (he != hipSuccess && !rc) {
+      g->msg[(size_t)me.rank] = std::string(what) + ": " + hipGetErrorString(he);
+      rc = LK_ERROR_DEVICE;
+    }
+  };
+  if (!up) {
+    if (me.probe[0]) {
+      hip(hipEventRecord(me.probe[0], cs), "hipEventRecord", up);
+      me.probe_valid[0] = true;
+    }
+    for (int i = 0; i < n_frames; ++i) {
+      FrameBuf &fb = which(me, i);
+      if (fb.consumed_valid) // the pyramid kernel of the frame this buffer held before
+        hip(hipStreamWaitEvent(cs, fb.consumed, 0), "hipStreamWaitEvent", up);
+    }
+    if (me.rank == 0) {
+      if (by_copy)
+        for (Member &q : g->m) { // the other ranks copied the previous frames out of this buffer
+          FrameBuf &fq = which(q, 0);
+          if (q.rank != 0 && fq.copied_valid)
+            hip(hipStreamWaitEvent(cs, fq.copied, 0), "hipStreamWaitEvent", up);
+        }
+      for (int i = 0; i < n_frames; ++i)
+        hip(hipMemcpy2DAsync(which(me, i).p, (size_t)cols, src(i), (size_t)step, (size_t)cols, (size_t)rows,
+                             on_device0 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, cs), "hipMemcpy2DAsync", up);
+      if (by_copy)
+        hip(hipEventRecord(f0.up, cs), "hipEventRecord", up);
+    }
+  }
+  if (int rc = g->agree(up)) // nobody enters the collective unless every member got this far (and rank 0's upload is enqueued)
+    return up ? up : rc;
+  if (!by_copy) {
     int rc = LK_ERROR_NONE;
-    const ncclResult_t ne = ncclBroadcast(me.d_frame[slot], me.d_frame[slot], bytes, ncclUint8, 0, me.comm, me.st);
+    const ncclResult_t ne = ncclBroadcast(f0.p, f0.p, (size_t)n_frames * bytes, ncclUint8, 0, me.comm, cs);
     if (ne != ncclSuccess) {
       g->msg[(size_t)me.rank] = std::string("ncclBroadcast: ") + ncclGetErrorString(ne);
       rc = LK_ERROR_DEVICE;
     }
     if (int all = g->agree(rc))
-      return collective_failed(g, me, all);
+      return collective_failed(g, me, rc ? rc : all);
   } else if (g->m.size() > 1) {
     int rc = LK_ERROR_NONE;
-    auto hip = [&](hipError_t he, const char *what) {
-      if (he != hipSuccess && !rc) {
-        g->msg[(size_t)me.rank] = std::string(what) + ": " + hipGetErrorString(he);
-        rc = LK_ERROR_DEVICE;
-      }
-    };
-    if (me.rank == 0)
-      hip(hipStreamSynchronize(me.st), "hipStreamSynchronize");
-    rc = g->agree(rc); // rank 0's pixels are there (or everybody knows they are not)
-    if (!rc && me.rank != 0) {
-      hip(hipMemcpyAsync(me.d_frame[slot], g->m[0].d_frame[slot], bytes, hipMemcpyDeviceToDevice, me.st), "hipMemcpyAsync");
-      hip(hipStreamSynchronize(me.st), "hipStreamSynchronize");
+    if (me.rank != 0) {
+      FrameBuf &r0 = which(g->m[0], 0);
+      hip(hipStreamWaitEvent(cs, r0.up, 0), "hipStreamWaitEvent", rc);
+      hip(hipMemcpyAsync(f0.p, r0.p, (size_t)n_frames * bytes, hipMemcpyDeviceToDevice, cs), "hipMemcpyAsync", rc);
+      hip(hipEventRecord(f0.copied, cs), "hipEventRecord", rc);
+      f0.copied_valid = !rc;
     }
-    if (int all = g->agree(rc)) // nobody reads rank 0's buffer any more
-      return all;
+    if (int all = g->agree(rc))
+      return rc ? rc : all;
   }
-  if (slot == LK_IMG_NXT) // the engine fills that slot on its own next-frame stream: the pixels must have arrived
-    GHIP(hipStreamSynchronize(me.st));
-  GLK(lk_set_image_device(me.e, slot, me.d_frame[slot], rows, cols, cols));
+  for (int i = 0; i < n_frames; ++i)
+    GHIP(hipEventRecord(which(me, i).arrived, cs));
+  if (me.probe[1])
+    GHIP(hipEventRecord(me.probe[1], cs));
+  for (int i = 0; i < n_frames; ++i) {
+    FrameBuf &fb = which(me, i);
+    if (int rc = fill(me, i, fb))
+      return rc;
+    fb.consumed_valid = true;
+  }
   return LK_ERROR_NONE;
 }
 
@@ -312,6 +395,8 @@ int lk_group_create(const lk_config *cfg, int n_devices, const int *devices, lk_
     for (int q = 0; q < r; ++q)
       g->loopback = g->loopback || devs[(size_t)q] == devs[(size_t)r];
   }
+  if (const char *f = std::getenv("LK_GROUP_FRAMES"))
+    g->copy_frames = std::string(f) == "copy";
   bool ok = true;
   for (int r = 0; r < n_devices && ok; ++r) {
     Member &me = g->m[(size_t)r];
@@ -321,7 +406,13 @@ int lk_group_create(const lk_config *cfg, int n_devices, const int *devices, lk_
     c.device = me.device;
     ok = lk_create(&c, &me.e) == LK_ERROR_NONE && hipSetDevice(me.device) == hipSuccess &&
          hipStreamCreateWithFlags(&me.st, hipStreamNonBlocking) == hipSuccess &&
+         hipStreamCreateWithFlags(&me.cst, hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&me.ev_solved, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&me.ev_gathered, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&me.ev_block, hipEventDisableTiming) == hipSuccess &&
          lk_set_stream(me.e, me.st) == LK_ERROR_NONE && lk_internal_set_defer_stale(me.e, 1) == LK_ERROR_NONE;
+    for (hipEvent_t &ev : me.probe)
+      ok = ok && hipEventCreate(&ev) == hipSuccess;
   }
   if (ok && !g->loopback) {
     std::vector<ncclComm_t> comms((size_t)n_devices);
@@ -356,16 +447,35 @@ void lk_group_destroy(lk_group *g) {
       (void)lk_synchronize(me.e);
     if (me.comm)
       (void)ncclCommDestroy(me.comm);
-    for (uint8_t *p : me.d_frame)
+    if (me.cst)
+      (void)hipStreamSynchronize(me.cst);
+    auto drop = [](FrameBuf &fb) {
+      if (fb.p)
+        (void)hipFree(fb.p);
+      for (hipEvent_t ev : {fb.arrived, fb.consumed, fb.up, fb.copied})
+        if (ev)
+          (void)hipEventDestroy(ev);
+    };
+    for (FrameBuf &fb : me.frame)
+      drop(fb);
+    for (FrameBuf &fb : me.ring) {
+      fb.p = nullptr; // (slices of d_ring)
+      drop(fb);
+    }
+    if (me.d_ring)
+      (void)hipFree(me.d_ring);
+    for (void *p : {(void *)me.d_guess, (void *)me.d_rec, (void *)me.d_all, (void *)me.d_stale, (void *)me.d_seq_rec, (void *)me.d_seq_all})
       if (p)
         (void)hipFree(p);
-    for (void *p : {(void *)me.d_guess, (void *)me.d_rec, (void *)me.d_all, (void *)me.d_stale})
-      if (p)
-        (void)hipFree(p);
+    for (hipEvent_t ev : {me.ev_solved, me.ev_gathered, me.ev_block, me.probe[0], me.probe[1], me.probe[2], me.probe[3]})
+      if (ev)
+        (void)hipEventDestroy(ev);
     if (me.e)
       lk_destroy(me.e);
     if (me.st)
       (void)hipStreamDestroy(me.st);
+    if (me.cst)
+      (void)hipStreamDestroy(me.cst);
   }
   delete g;
 }
@@ -413,21 +523,18 @@ static int set_image_any(lk_group *g, int slot, const void *src, bool on_device0
   const size_t bytes = (size_t)rows * (size_t)cols;
   bool grow = false;
   for (const Member &me : g->m)
-    grow = grow || me.frame_cap[slot] < bytes;
+    grow = grow || me.frame[slot].cap < bytes || !me.frame[slot].arrived;
   if (grow)
-    if (int rc = g->run([=](Member &me) -> int { return ensure_frame(g, me, slot, bytes); }))
+    if (int rc = g->run([=](Member &me) -> int { return ensure_frame(g, me, me.frame[slot], bytes); }))
       return rc;
   return g->run([=](Member &me) -> int {
-    int up = LK_ERROR_NONE;
-    if (me.rank == 0 && me.device_ok) {
-      const hipError_t he = hipMemcpy2DAsync(me.d_frame[slot], (size_t)cols, src, (size_t)step, (size_t)cols, (size_t)rows,
-                                             on_device0 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, me.st);
-      if (he != hipSuccess) {
-        g->msg[(size_t)me.rank] = std::string("hipMemcpy2DAsync: ") + hipGetErrorString(he);
-        up = LK_ERROR_DEVICE;
-      }
-    }
-    return distribute_frame(g, me, slot, rows, cols, up);
+    return distribute_frames(g, me, 1, [slot](Member &q, int) -> FrameBuf & { return q.frame[slot]; },
+                             [src](int) { return src; }, on_device0, rows, cols, step,
+                             [=](Member &q, int, FrameBuf &fb) -> int {
+                               Member &me = q; // (GLK names `me`)
+                               GLK(lk_internal_set_image_device_after(q.e, slot, fb.p, rows, cols, cols, fb.arrived, fb.consumed));
+                               return LK_ERROR_NONE;
+                             });
   }, true);
 }
 int lk_group_set_image(lk_group *g, int slot, const uint8_t *host_pixels, int rows, int cols, int step) {
@@ -544,6 +651,8 @@ int lk_group_commit_sectors(lk_group *g) {
     GLK(lk_commit_sectors(me.e));
     if (me.cap < (size_t)cap) {
       GLK(lk_synchronize(me.e));
+      GHIP(hipStreamSynchronize(me.cst));
+      me.gathered_valid = false;
       for (void *p : {(void *)me.d_guess, (void *)me.d_rec, (void *)me.d_all})
         if (p)
           GHIP(hipFree(p));
@@ -566,12 +675,85 @@ int lk_group_commit_sectors(lk_group *g) {
 }
 
 // ---- the solve ----------------------------------------------------------------------------------
+// The exchange of one solve's (or one window's) records, on the communication stream behind `me.ev_solved`:
+// send = this member's padded block, recv = n blocks; frames = 1 (one pair) or the window's frame count.
+static int gather_records(lk_group *g, Member &me, lk_result *send, lk_result *recv, size_t block_bytes, int frames, int rc_before,
+                          lk_result *out) {
+  const int n = (int)g->m.size();
+  hipStream_t cs = comm_stream(me);
+  int rc = rc_before;
+  auto hip = [&](hipError_t he, const char *what) {
+    if (he != hipSuccess && !rc) {
+      g->msg[(size_t)me.rank] = std::string(what) + ": " + hipGetErrorString(he);
+      rc = LK_ERROR_DEVICE;
+    }
+  };
+  if (int all = g->agree(rc)) // nobody enqueues the all-gather unless every member's solve is on its way
+    return rc ? rc : all;
+  hip(hipStreamWaitEvent(cs, me.ev_solved, 0), "hipStreamWaitEvent");
+  if (!g->loopback) {
+    if (!rc) {
+      const ncclResult_t ne = ncclAllGather(send, recv, block_bytes, ncclUint8, me.comm, cs);
+      if (ne != ncclSuccess) {
+        g->msg[(size_t)me.rank] = std::string("ncclAllGather: ") + ncclGetErrorString(ne);
+        rc = LK_ERROR_DEVICE;
+      }
+    }
+    if (int all = g->agree(rc))
+      return collective_failed(g, me, rc ? rc : all);
+  } else {
+    // rehearsal transport: every member copies its block into everybody's receive buffer and tells them by an event
+    for (int q = 0; q < n && !rc; ++q) {
+      lk_result *dst = frames > 1 ? g->m[(size_t)q].d_seq_all : g->m[(size_t)q].d_all;
+      hip(hipMemcpyAsync((char *)dst + (size_t)me.rank * block_bytes, send, block_bytes, hipMemcpyDeviceToDevice, cs), "hipMemcpyAsync");
+    }
+    hip(hipEventRecord(me.ev_block, cs), "hipEventRecord");
+    rc = g->agree(rc); // every member's event is on its stream (or everybody knows a copy failed)
+    if (!rc)
+      for (int q = 0; q < n; ++q)
+        if (q != me.rank)
+          hip(hipStreamWaitEvent(cs, g->m[(size_t)q].ev_block, 0), "hipStreamWaitEvent");
+    if (int all = g->agree(rc)) // (nobody re-records its event - the next exchange - before everybody has waited for it)
+      return rc ? rc : all;
+  }
+  // reference-order mode: the stale iteration counts, over the gathered records in the order the reference solves
+  // (global sector order, frame by frame) with the group's own carry; every member resolves its copy - all copies end up
+  // identical - and takes its own resolved block back into its engine's record buffer
+  if (lk_internal_reference_order(me.e) > 0) {
+    if (!me.d_stale) {
+      GHIP(hipMalloc((void **)&me.d_stale, 2 * sizeof(int)));
+      GHIP(hipMemsetAsync(me.d_stale, 0, 2 * sizeof(int), cs));
+    }
+    if (frames > 1)
+      GHIP(lk_launch_stale_iterations_window(recv, g->S, n, g->cap, frames, me.d_stale + me.stale_par, me.d_stale + (me.stale_par ^ 1), cs));
+    else
+      GHIP(lk_launch_stale_iterations_blocks(recv, g->S, n, g->cap, me.d_stale + me.stale_par, me.d_stale + (me.stale_par ^ 1), cs));
+    me.stale_par ^= 1;
+    const void *d_own = nullptr;
+    GLK(lk_get_results_device(me.e, &d_own));
+    const lk_result *mine = (const lk_result *)((const char *)recv + (size_t)me.rank * block_bytes) + (size_t)(frames - 1) * (size_t)g->cap;
+    GHIP(hipMemcpyAsync(const_cast<void *>(d_own), mine, (size_t)me.count * sizeof(lk_result), hipMemcpyDeviceToDevice, cs));
+  }
+  if (out && me.rank == 0) { // global sector order: block q starts at rank q's first sector
+    for (int q = 0; q < n; ++q) {
+      int first, count;
+      shard(g->S, q, n, first, count);
+      GHIP(hipMemcpy2DAsync(out + first, (size_t)g->S * sizeof(lk_result), (const char *)recv + (size_t)q * block_bytes,
+                            (size_t)g->cap * sizeof(lk_result), (size_t)count * sizeof(lk_result), (size_t)frames, hipMemcpyDeviceToHost, cs));
+    }
+  }
+  GHIP(hipEventRecord(me.ev_gathered, cs));
+  me.gathered_valid = true;
+  if (out && me.rank == 0)
+    GHIP(hipStreamSynchronize(cs));
+  return LK_ERROR_NONE;
+}
+
 int lk_group_correlate_all(lk_group *g, const float *guesses, lk_result *out) {
   if (!g)
     return LK_ERROR_BAD_DOMAIN;
   if (!g->committed)
     return g->fail(LK_ERROR_BAD_DOMAIN, "lk_group_correlate_all: sectors are not committed");
-  const int n = (int)g->m.size();
   const size_t block = (size_t)g->cap * sizeof(lk_result);
   return g->run([=](Member &me) -> int {
     // phase 1 - what can fail on this member alone: the guess upload, the engine's deferred re-commit /
@@ -586,64 +768,212 @@ int lk_group_correlate_all(lk_group *g, const float *guesses, lk_result *out) {
           g->msg[(size_t)me.rank] = "LK_GROUP_FAULT: injected failure before the all-gather";
           return LK_ERROR_DEVICE;
         }
+      // the previous exchange still reads the padded block (and, in reference-order mode, writes the engine's records)
+      const bool ordered = lk_internal_reference_order(me.e) > 0;
+      if (me.gathered_valid && ordered)
+        GHIP(hipStreamWaitEvent(me.st, me.ev_gathered, 0));
       if (guesses)
         GHIP(hipMemcpyAsync(me.d_guess, guesses + 6 * (size_t)me.first, 6 * (size_t)me.count * sizeof(float),
                             hipMemcpyHostToDevice, me.st));
+      GHIP(hipEventRecord(me.probe[2], me.st));
       GLK(lk_correlate_all_device(me.e, guesses ? me.d_guess : nullptr, nullptr));
+      GHIP(hipEventRecord(me.probe[3], me.st));
+      me.probe_valid[1] = true;
       GLK(lk_get_results_device(me.e, &d_own));
+      if (me.gathered_valid && !ordered)
+        GHIP(hipStreamWaitEvent(me.st, me.ev_gathered, 0));
       GHIP(hipMemcpyAsync(me.d_rec, d_own, (size_t)me.count * sizeof(lk_result), hipMemcpyDeviceToDevice, me.st)); // (the padded all-gather block)
+      GHIP(hipEventRecord(me.ev_solved, me.st));
       return LK_ERROR_NONE;
     }();
-    if (int all = g->agree(rc)) // nobody enqueues the all-gather unless every member's solve is on its way
-      return rc ? rc : all;
-    // phase 2 - the exchange
-    if (!g->loopback) {
-      const ncclResult_t ne = ncclAllGather(me.d_rec, me.d_all, block, ncclUint8, me.comm, me.st);
-      if (ne != ncclSuccess) {
-        g->msg[(size_t)me.rank] = std::string("ncclAllGather: ") + ncclGetErrorString(ne);
-        rc = LK_ERROR_DEVICE;
+    // phases 2, 3 - the exchange, behind the solve on the communication stream
+    return gather_records(g, me, me.d_rec, me.d_all, block, 1, rc, out);
+  }, true);
+}
+
+// ---- frame-pipelined windows (lk_correlate_sequence_async on every member) --------------------------------------
+int lk_group_sequence_reserve(lk_group *g, int n_slots) {
+  if (!g)
+    return LK_ERROR_BAD_DOMAIN;
+  if (n_slots < 1 || n_slots > 4096)
+    return g->fail(LK_ERROR_BAD_DOMAIN, "lk_group_sequence_reserve: n_slots must be in 1..4096");
+  return g->run([=](Member &me) -> int {
+    GLK(lk_sequence_reserve(me.e, n_slots));
+    if ((int)me.ring.size() < n_slots) { // (the pixels' allocation follows with the first frame: its size is not known yet)
+      GLK(lk_synchronize(me.e));
+      GHIP(hipStreamSynchronize(me.cst));
+      if (me.d_ring)
+        GHIP(hipFree(me.d_ring));
+      me.d_ring = nullptr;
+      me.ring_slot_bytes = 0;
+      me.ring.resize((size_t)n_slots);
+      for (FrameBuf &fb : me.ring) {
+        fb.p = nullptr;
+        fb.cap = 0;
+        fb.consumed_valid = fb.copied_valid = false;
       }
-      if (int all = g->agree(rc))
-        return collective_failed(g, me, rc ? rc : all);
-    } else {
-      auto hip = [&](hipError_t he, const char *what) {
-        if (he != hipSuccess && !rc) {
-          g->msg[(size_t)me.rank] = std::string(what) + ": " + hipGetErrorString(he);
-          rc = LK_ERROR_DEVICE;
-        }
-      };
-      hip(hipStreamSynchronize(me.st), "hipStreamSynchronize");
-      rc = g->agree(rc); // every block is final (or everybody knows one is not)
-      if (!rc) {
-        for (int q = 0; q < n; ++q)
-          hip(hipMemcpyAsync((char *)g->m[(size_t)q].d_all + (size_t)me.rank * block, me.d_rec, block,
-                             hipMemcpyDeviceToDevice, me.st), "hipMemcpyAsync");
-        hip(hipStreamSynchronize(me.st), "hipStreamSynchronize");
-      }
-      if (int all = g->agree(rc)) // everybody's d_all is complete
-        return rc ? rc : all;
-    }
-    // phase 3 - reference-order mode: the stale iteration counts, over the gathered records in global sector
-    // order with the group's own carry (every member resolves its copy; all copies end up identical)
-    if (lk_internal_reference_order(me.e) > 0) {
-      if (!me.d_stale) {
-        GHIP(hipMalloc((void **)&me.d_stale, 2 * sizeof(int)));
-        GHIP(hipMemsetAsync(me.d_stale, 0, 2 * sizeof(int), me.st));
-      }
-      GHIP(lk_launch_stale_iterations_blocks(me.d_all, g->S, n, g->cap, me.d_stale + me.stale_par, me.d_stale + (me.stale_par ^ 1), me.st));
-      me.stale_par ^= 1;
-    }
-    if (out && me.rank == 0) { // global sector order: block r starts at rank r's first sector
-      for (int q = 0; q < n; ++q) {
-        int first, count;
-        shard(g->S, q, n, first, count);
-        GHIP(hipMemcpyAsync(out + first, (const char *)me.d_all + (size_t)q * block, (size_t)count * sizeof(lk_result),
-                            hipMemcpyDeviceToHost, me.st));
-      }
-      GHIP(hipStreamSynchronize(me.st));
     }
     return LK_ERROR_NONE;
+  });
+}
+
+static int ensure_ring(lk_group *g, Member &me, size_t bytes) {
+  for (FrameBuf &fb : me.ring)
+    if (int rc = ensure_events(g, me, fb))
+      return rc;
+  if (me.d_ring && me.ring_slot_bytes >= bytes)
+    return LK_ERROR_NONE;
+  GLK(lk_synchronize(me.e));
+  GHIP(hipStreamSynchronize(me.cst));
+  if (me.d_ring)
+    GHIP(hipFree(me.d_ring));
+  me.d_ring = nullptr;
+  me.ring_slot_bytes = 0;
+  GHIP(hipMalloc((void **)&me.d_ring, me.ring.size() * bytes));
+  me.ring_slot_bytes = bytes;
+  for (size_t i = 0; i < me.ring.size(); ++i) {
+    me.ring[i].p = me.d_ring + i * bytes;
+    me.ring[i].cap = bytes;
+    me.ring[i].consumed_valid = me.ring[i].copied_valid = false;
+  }
+  return LK_ERROR_NONE;
+}
+
+// n frames into the ring slots first_slot .. first_slot + n - 1 (no wrap-around: split the call), in ONE transfer
+static int sequence_set_frames_any(lk_group *g, int first_slot, int n_frames, const std::function<const void *(int)> &src, bool on_device0,
+                                   int rows, int cols, int step) {
+  if (!g)
+    return LK_ERROR_BAD_DOMAIN;
+  if (n_frames < 1 || first_slot < 0 || first_slot + n_frames > (int)g->m[0].ring.size() || rows < 1 || cols < 1 || step < cols)
+    return g->fail(LK_ERROR_BAD_DOMAIN, "lk_group_sequence_set_frames: bad arguments / slots outside the ring (lk_group_sequence_reserve)");
+  for (int i = 0; i < n_frames; ++i)
+    if (!src(i))
+      return g->fail(LK_ERROR_BAD_DOMAIN, "lk_group_sequence_set_frames: null frame");
+  const size_t bytes = (size_t)rows * (size_t)cols;
+  bool grow = false;
+  for (const Member &me : g->m)
+    grow = grow || me.ring_slot_bytes != bytes || !me.ring[0].arrived;
+  if (grow) // (one frame size per ring; allocations in a job of their own: see set_image_any)
+    if (int rc = g->run([=](Member &me) -> int { return ensure_ring(g, me, bytes); }))
+      return rc;
+  return g->run([=](Member &me) -> int {
+    return distribute_frames(g, me, n_frames, [first_slot](Member &q, int i) -> FrameBuf & { return q.ring[(size_t)(first_slot + i)]; },
+                             src, on_device0, rows, cols, step,
+                             [=](Member &q, int i, FrameBuf &fb) -> int {
+                               Member &me = q;
+                               GLK(lk_internal_sequence_set_frame_device_after(q.e, first_slot + i, fb.p, rows, cols, cols, fb.arrived, fb.consumed));
+                               return LK_ERROR_NONE;
+                             });
   }, true);
+}
+int lk_group_sequence_set_frames(lk_group *g, int first_slot, int n_frames, const uint8_t *const *host_pixels, int rows, int cols, int step) {
+  if (!host_pixels)
+    return LK_ERROR_BAD_DOMAIN;
+  return sequence_set_frames_any(g, first_slot, n_frames, [host_pixels](int i) -> const void * { return host_pixels[i]; }, false, rows, cols, step);
+}
+int lk_group_sequence_set_frames_device(lk_group *g, int first_slot, int n_frames, const void *device0_pixels, int rows, int cols, int step) {
+  if (!device0_pixels)
+    return LK_ERROR_BAD_DOMAIN;
+  const char *base = (const char *)device0_pixels;
+  const size_t pitch = (size_t)rows * (size_t)step; // frames back to back
+  return sequence_set_frames_any(g, first_slot, n_frames, [base, pitch](int i) -> const void * { return base + (size_t)i * pitch; }, true, rows, cols, step);
+}
+
+int lk_group_correlate_sequence_async(lk_group *g, int und_slot, int first_slot, int n_frames, int reference_previous,
+                                      int constant_velocity) {
+  if (!g)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!g->committed)
+    return g->fail(LK_ERROR_BAD_DOMAIN, "lk_group_correlate_sequence_async: sectors are not committed");
+  if (n_frames < 1)
+    return g->fail(LK_ERROR_BAD_DOMAIN, "lk_group_correlate_sequence_async: no frames");
+  return g->run([=](Member &me) -> int {
+    if (me.seq_frames)
+      return LK_ERROR_BAD_DOMAIN;
+    GHIP(hipEventRecord(me.probe[2], me.st));
+    GLK(lk_correlate_sequence_async(me.e, und_slot, first_slot, n_frames, reference_previous, constant_velocity, 0));
+    GHIP(hipEventRecord(me.probe[3], me.st));
+    me.probe_valid[1] = true;
+    me.seq_frames = n_frames;
+    return LK_ERROR_NONE;
+  });
+}
+
+int lk_group_wait_sequence(lk_group *g, lk_result *out) {
+  if (!g)
+    return LK_ERROR_BAD_DOMAIN;
+  const int n = (int)g->m.size();
+  int frames = 0;
+  for (const Member &me : g->m)
+    frames = std::max(frames, me.seq_frames);
+  if (frames < 1)
+    return g->fail(LK_ERROR_BAD_DOMAIN, "lk_group_wait_sequence: no window outstanding");
+  const size_t block = (size_t)frames * (size_t)g->cap * sizeof(lk_result);
+  bool grow = false;
+  for (const Member &me : g->m)
+    grow = grow || me.seq_frames_cap < (size_t)frames;
+  if (grow) // (allocations in a job of their own: see set_image_any)
+    if (int rc = g->run([=](Member &me) -> int {
+          GHIP(hipStreamSynchronize(me.cst));
+          for (void *p : {(void *)me.d_seq_rec, (void *)me.d_seq_all})
+            if (p)
+              GHIP(hipFree(p));
+          me.d_seq_rec = me.d_seq_all = nullptr;
+          me.seq_frames_cap = 0;
+          GHIP(hipMalloc((void **)&me.d_seq_rec, block));
+          GHIP(hipMalloc((void **)&me.d_seq_all, (size_t)n * block));
+          GHIP(hipMemsetAsync(me.d_seq_rec, 0, block, me.st)); // (the padding records stay zero)
+          me.seq_frames_cap = (size_t)frames;
+          return LK_ERROR_NONE;
+        }))
+      return rc;
+  return g->run([=](Member &me) -> int {
+    int rc = [&]() -> int {
+      if (!me.device_ok || me.seq_frames != frames)
+        return LK_ERROR_DEVICE;
+      GLK(lk_wait_sequence(me.e, nullptr)); // (this member's window is solved; its sequence state is committed)
+      const void *d_win = nullptr;
+      GLK(lk_get_sequence_results_device(me.e, &d_win, nullptr));
+      if (me.gathered_valid)
+        GHIP(hipStreamWaitEvent(me.st, me.ev_gathered, 0)); // (the previous exchange read the padded block)
+      GHIP(hipMemcpy2DAsync(me.d_seq_rec, (size_t)g->cap * sizeof(lk_result), d_win, (size_t)me.count * sizeof(lk_result),
+                            (size_t)me.count * sizeof(lk_result), (size_t)frames, hipMemcpyDeviceToDevice, me.st));
+      GHIP(hipEventRecord(me.ev_solved, me.st));
+      return LK_ERROR_NONE;
+    }();
+    me.seq_frames = 0;
+    return gather_records(g, me, me.d_seq_rec, me.d_seq_all, block, frames, rc, out);
+  }, true);
+}
+
+int lk_group_sequence_records_device(lk_group *g, int rank, const void **d_records) {
+  if (!g || !d_records || rank < 0 || rank >= (int)g->m.size() || !g->m[(size_t)rank].d_seq_all)
+    return LK_ERROR_BAD_DOMAIN;
+  *d_records = g->m[(size_t)rank].d_seq_all;
+  return LK_ERROR_NONE;
+}
+
+// what overlapped on `rank`'s device: ms_out[0] = duration of the last frame transfer (communication stream), [1] = of the
+// last solve / window launch chain (solve stream), [2] = transfer begin - solve begin, [3] = solve end - transfer end
+// (both positive: the transfer ran inside the solve).  Waits for both.
+int lk_group_probe_overlap(lk_group *g, int rank, float *ms_out) {
+  if (!g || !ms_out || rank < 0 || rank >= (int)g->m.size())
+    return LK_ERROR_BAD_DOMAIN;
+  return g->run([=](Member &me) -> int {
+    if (me.rank != rank)
+      return LK_ERROR_NONE;
+    if (!me.probe_valid[0] || !me.probe_valid[1]) {
+      g->msg[(size_t)me.rank] = "lk_group_probe_overlap: no frame transfer or no solve yet";
+      return LK_ERROR_BAD_DOMAIN;
+    }
+    GHIP(hipEventSynchronize(me.probe[1]));
+    GHIP(hipEventSynchronize(me.probe[3]));
+    GHIP(hipEventElapsedTime(&ms_out[0], me.probe[0], me.probe[1]));
+    GHIP(hipEventElapsedTime(&ms_out[1], me.probe[2], me.probe[3]));
+    GHIP(hipEventElapsedTime(&ms_out[2], me.probe[2], me.probe[0]));
+    GHIP(hipEventElapsedTime(&ms_out[3], me.probe[1], me.probe[3]));
+    return LK_ERROR_NONE;
+  });
 }
 
 int lk_group_adjust_initial_guess(lk_group *g, int frame, int constant_velocity, const float *global_guess,
@@ -674,6 +1004,7 @@ int lk_group_synchronize(lk_group *g) {
   return g->run([=](Member &me) -> int {
     GLK(lk_synchronize(me.e));
     GHIP(hipStreamSynchronize(me.st));
+    GHIP(hipStreamSynchronize(me.cst));
     return LK_ERROR_NONE;
   });
 }

@@ -3550,6 +3550,33 @@ __global__ void lk_stale_iterations_blocks_kernel(lk_result *r, int n, int n_ran
     *carry_out = v;
 }
 
+// ... and over the gathered records of a frame-pipelined WINDOW of a group: n_ranks blocks of [frames][cap] records, in the
+// order the reference solves them - frame 0's sectors 0 .. S-1, then frame 1's, ...
+__device__ __forceinline__ size_t stale_window_pos(long long t, int n, int n_ranks, int cap, int frames) {
+  const int f = (int)(t / n), s = (int)(t - (long long)f * n);
+  const size_t in_frame = stale_block_pos(s, n, n_ranks, cap); // q * cap + (s - first_q)
+  const size_t q = in_frame / (size_t)cap, k = in_frame - q * (size_t)cap;
+  return (q * (size_t)frames + (size_t)f) * (size_t)cap + k;
+}
+__global__ void lk_stale_iterations_window_kernel(lk_result *r, int n, int n_ranks, int cap, int frames, const int *carry_in, int *carry_out) {
+  const long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, total = (long long)n * frames;
+  if (t0 >= total)
+    return;
+  int *it = &r[stale_window_pos(t0, n, n_ranks, cap, frames)].iterations;
+  int v = __hip_atomic_load(it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (v == kStaleIterations) {
+    long long t = t0 - 1;
+    while (t >= 0 && (v = __hip_atomic_load(&r[stale_window_pos(t, n, n_ranks, cap, frames)].iterations, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT)) == kStaleIterations)
+      --t;
+    if (t < 0)
+      v = *carry_in;
+    __hip_atomic_store(it, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (t0 == total - 1)
+    *carry_out = v;
+}
+
 // ---- the sequential float mean of an INTEGER sample list, evaluated in parallel, bit for bit ----
 // pyramid_class.cpp:325-340 adds the coordinates into one running float per axis, in list order.
 // For a 4.2 M-sample blob that chain is 4.2 M dependent additions (tens of ms for one wavefront).
@@ -3975,6 +4002,16 @@ hipError_t lk_launch_stale_iterations_blocks(lk_result *all, int n, int n_ranks,
     return hipSuccess;
   hipLaunchKernelGGL(lk_stale_iterations_blocks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, all, n, n_ranks,
                      cap, carry_in, carry_out);
+  return hipGetLastError();
+}
+
+hipError_t lk_launch_stale_iterations_window(lk_result *all, int n, int n_ranks, int cap, int frames, const int *carry_in,
+                                             int *carry_out, hipStream_t st) {
+  if (n <= 0 || frames <= 0)
+    return hipSuccess;
+  const long long total = (long long)n * frames;
+  hipLaunchKernelGGL(lk_stale_iterations_window_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, all, n, n_ranks, cap,
+                     frames, carry_in, carry_out);
   return hipGetLastError();
 }
 

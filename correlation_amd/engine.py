@@ -296,6 +296,9 @@ class HipCorrelationEngine:
         self._chk(self.lib.lk_get_sequence_results_device(self._h, C.byref(r), C.byref(g)))
         return r.value, g.value
 
+    def copy_sequence_records_device(self, dst_ptr, pitch_records):
+        self._chk(self.lib.lk_copy_sequence_records_device(self._h, C.c_void_p(dst_ptr), C.c_size_t(int(pitch_records))))
+
     def sequence_guesses(self):
         g = np.zeros((self._seq_frames, self.n_sectors, 6), np.float32)
         self._chk(self.lib.lk_get_sequence_guesses(self._h, _ffi.fptr(g)))

@@ -122,6 +122,37 @@ class HipCorrelationGroup:
         self._chk(self.lib.lk_group_adjust_initial_guess(self._h, frame, int(bool(constant_velocity)), _ffi.fptr(g),
                                                          float(global_center[0]), float(global_center[1])))
 
+    # ---- frame-pipelined windows ----------------------------------------------------------
+    def sequence_reserve(self, n_slots):
+        self._chk(self.lib.lk_group_sequence_reserve(self._h, int(n_slots)))
+
+    def sequence_set_frames(self, first_slot, frames):
+        """host frames (a list of 2-D u8 arrays of one size) into consecutive ring slots, in one transfer"""
+        arrs = [np.ascontiguousarray(f, np.uint8) for f in frames]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        self._chk(self.lib.lk_group_sequence_set_frames(self._h, int(first_slot), len(arrs), ptrs, arrs[0].shape[0],
+                                                        arrs[0].shape[1], arrs[0].strides[0]))
+
+    def sequence_set_frames_device(self, first_slot, n_frames, dev_ptr, rows, cols, step=None):
+        self._chk(self.lib.lk_group_sequence_set_frames_device(self._h, int(first_slot), int(n_frames), C.c_void_p(dev_ptr), rows, cols,
+                                                               step or cols))
+
+    def correlate_sequence_async(self, n_frames, first_slot=0, und_slot=-1, reference_previous=False, constant_velocity=True):
+        self._seq_frames = int(n_frames)
+        self._chk(self.lib.lk_group_correlate_sequence_async(self._h, int(und_slot), int(first_slot), int(n_frames),
+                                                             int(bool(reference_previous)), int(bool(constant_velocity))))
+
+    def wait_sequence(self, fetch=True):
+        out = np.zeros((self._seq_frames, self.n_sectors), _ffi.RESULT_DTYPE) if fetch else None
+        self._chk(self.lib.lk_group_wait_sequence(self._h, out.ctypes.data_as(C.c_void_p) if fetch else None))
+        return out
+
+    def probe_overlap(self, rank=0):
+        """(transfer ms, solve ms, transfer begin - solve begin, solve end - transfer end) on `rank`'s device"""
+        ms = np.zeros(4, np.float32)
+        self._chk(self.lib.lk_group_probe_overlap(self._h, int(rank), _ffi.fptr(ms)))
+        return ms
+
     def synchronize(self):
         self._chk(self.lib.lk_group_synchronize(self._h))
 

@@ -313,6 +313,9 @@ int lk_correlate_sequence_async(lk_engine *e, int und_slot, int first_slot, int 
 int lk_wait_sequence(lk_engine *e, lk_result *out);
 /* the window's records [n_frames][S] and (flags & 2) guesses [n_frames][S][6] in device memory */
 int lk_get_sequence_results_device(lk_engine *e, const void **d_records, const void **d_guesses);
+/* the last window's records into a caller's device buffer, frame f at d_dst + f * dst_pitch_records records
+ * (dst_pitch_records >= S; the padded blocks of an all-gather), asynchronously on the engine's stream */
+int lk_copy_sequence_records_device(lk_engine *e, void *d_dst, size_t dst_pitch_records);
 /* 1: the last window ran on the frame-pipelined instances, 0: frame after frame */
 int lk_sequence_is_pipelined(lk_engine *e);
 /* (flags & 2) the guesses every frame of the last window started from, [n_frames][S][6], to the host */

@@ -19,6 +19,12 @@
  *    broadcasting the 1.33x larger pyramid);
  *  - per solve: no collective inside; the 48-byte records are ncclAllGather-ed in equal padded
  *    blocks and handed to the caller in global sector order;
+ *  - transfers run on a communication stream per member, ordered against the solves by events: the
+ *    broadcast of the next frame (LK_IMG_NXT, or the next window's ring slots) travels while the current
+ *    pair / window is being solved - the reference's prefetch (manager_class.cpp:1438-1447) across GPUs -
+ *    and the records of one solve leave while the next one runs (LK_GROUP_FRAMES=copy: the frames by
+ *    device-to-device copies from device 0's buffer - the copy engines over the point-to-point xGMI links,
+ *    no compute unit needed - instead of ncclBroadcast);
  *  - sequence state (guess history for the constant-velocity guess, manager_class.cpp:2677-2686,
  *    moved sample lists) stays with the engine that owns the sector: a tracked sequence moves
  *    nothing between GPUs but the new frame and the records.
@@ -97,6 +103,35 @@ int lk_group_correlate_all(lk_group *g, const float *guesses, lk_result *out);
 /* managerClass::adjust_initial_guess on every member's own sectors (lk_adjust_initial_guess) */
 int lk_group_adjust_initial_guess(lk_group *g, int frame, int constant_velocity, const float *global_guess,
                                   float global_cx, float global_cy);
+/* ---- frame-pipelined windows of a sequence (lk_correlate_sequence_async on every member) -- */
+/* Every member keeps a ring of n_slots resident deformed frames (lk_sequence_reserve); the frames of a whole window
+ * travel from device 0 to the others in ONE transfer on the members' communication streams - while the window before
+ * is being solved - and every member solves the window for ITS block of sectors, each sector advancing through the
+ * frames on its own (include/lk_engine.h, "frame-pipelined windows").  Per window the group moves n_frames frames out
+ * and one all-gather of n_frames x S records back; guess history never leaves the owning engine
+ * (manager_class.cpp:1380-1496, :1438-1447, :2677-2699). */
+int lk_group_sequence_reserve(lk_group *g, int n_slots);
+/* n_frames frames into the ring slots first_slot .. first_slot + n_frames - 1 (no wrap-around: split the call):
+ * host frames (one pointer each), or frames back to back in device 0's memory (frame pitch = rows * step bytes).
+ * Returns when the transfer is enqueued; ordered against the solves by events, not by the host. */
+int lk_group_sequence_set_frames(lk_group *g, int first_slot, int n_frames, const uint8_t *const *host_pixels, int rows, int cols,
+                                 int step);
+int lk_group_sequence_set_frames_device(lk_group *g, int first_slot, int n_frames, const void *device0_pixels, int rows, int cols,
+                                        int step);
+/* lk_correlate_sequence_async on every member (frame 0 of the window from the members' engine-held guesses:
+ * lk_group_adjust_initial_guess); does not wait */
+int lk_group_correlate_sequence_async(lk_group *g, int und_slot, int first_slot, int n_frames, int reference_previous,
+                                      int constant_velocity);
+/* waits for every member's window, all-gathers the records (blocks of [n_frames][lk_group_block_records()] per
+ * member) and hands them over in global sector order: out [n_frames][S] host records, or NULL = leave them on the
+ * devices (lk_group_sequence_records_device; lk_group_synchronize waits for the exchange) */
+int lk_group_wait_sequence(lk_group *g, lk_result *out);
+int lk_group_sequence_records_device(lk_group *g, int rank, const void **d_records);
+/* what overlapped on `rank`'s device (HIP event times, ms): [0] duration of the last frame transfer on the
+ * communication stream, [1] of the last solve / window on the solve stream, [2] transfer begin - solve begin,
+ * [3] solve end - transfer end (both positive: the transfer ran inside the solve).  Waits for both. */
+int lk_group_probe_overlap(lk_group *g, int rank, float *ms4);
+
 /* device pointer (on `rank`'s device) of the gathered records: lk_group_size() blocks of
  * lk_group_block_records() records each, block r holding rank r's sectors first */
 int lk_group_records_device(lk_group *g, int rank, const void **d_records);

@@ -33,6 +33,13 @@ struct lk_engine {
   std::vector<float> guess, last_p, prev_p; // [S][6], engine-held (lk_adjust_initial_guess)
   std::vector<lk_result> pending, own_records;
   bool outstanding = false;
+  // frame-pipelined windows: the ring holds the image checksums; a window is the loop of one-pair solves
+  std::vector<unsigned> ring_sum;
+  std::vector<char> ring_valid;
+  std::vector<lk_result> win_records;
+  std::vector<float> win_guesses;
+  int win_frames = 0;
+  bool win_outstanding = false;
   std::string err;
 };
 static std::string g_journal;
@@ -320,6 +327,83 @@ int lk_correlate_all_async(lk_engine *e) {
   }
   e->outstanding = true;
   J("correlate_all_async S=%zu", S);
+  return 0;
+}
+int lk_sequence_reserve(lk_engine *e, int n_slots) {
+  if (!e || n_slots < 1)
+    return LK_ERROR_BAD_DOMAIN;
+  if ((int)e->ring_sum.size() < n_slots) {
+    e->ring_sum.resize((size_t)n_slots, 0u);
+    e->ring_valid.resize((size_t)n_slots, 0);
+  }
+  J("sequence_reserve %d", n_slots);
+  return 0;
+}
+int lk_sequence_set_frame(lk_engine *e, int slot, const uint8_t *px, int rows, int cols, int step) {
+  if (!e || slot < 0 || slot >= (int)e->ring_sum.size() || !px)
+    return LK_ERROR_BAD_DOMAIN;
+  unsigned s = 0;
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c)
+      s = s * 31u + px[(size_t)r * step + c];
+  e->ring_sum[(size_t)slot] = s;
+  e->ring_valid[(size_t)slot] = 1;
+  return 0; // (no journal line: a helper thread calls this while the caller's thread writes the journal)
+}
+int lk_correlate_sequence_async(lk_engine *e, int und_slot, int first_slot, int n_frames, int reference_previous, int cv, int flags) {
+  const int R = (int)e->ring_sum.size();
+  if (!e->committed || e->outstanding || e->win_outstanding || n_frames < 1 || n_frames > R || first_slot < 0 || first_slot >= R)
+    return LK_ERROR_BAD_DOMAIN;
+  const size_t S = e->hs.size();
+  if (e->guess.size() != 6 * S)
+    e->guess.assign(6 * S, 0.f);
+  e->last_p.resize(6 * S, 0.f);
+  e->prev_p.resize(6 * S, 0.f);
+  e->win_records.assign((size_t)n_frames * S, lk_result{});
+  e->win_guesses.assign((size_t)n_frames * 6 * S, 0.f);
+  const unsigned keep_und = e->sum[0], keep_def = e->sum[1];
+  for (int f = 0; f < n_frames; ++f) {
+    const int slot = (first_slot + f) % R;
+    if (!e->ring_valid[(size_t)slot])
+      return LK_ERROR_BAD_DOMAIN;
+    if (f == 0 && und_slot >= 0)
+      e->sum[0] = e->ring_sum[(size_t)und_slot];
+    else if (f > 0 && reference_previous)
+      e->sum[0] = e->ring_sum[(size_t)((first_slot + f - 1) % R)];
+    e->sum[1] = e->ring_sum[(size_t)slot];
+    for (size_t s = 0; s < S; ++s) {
+      if (f > 0)
+        for (int i = 0; i < 6; ++i) { // adjust_initial_guess's rule, per sector
+          const float r = e->last_p[6 * s + i], q = e->prev_p[6 * s + i];
+          e->guess[6 * s + i] = cv ? r + (r - q) : r;
+          e->prev_p[6 * s + i] = r;
+        }
+      std::memcpy(&e->win_guesses[((size_t)f * S + s) * 6], &e->guess[6 * s], 6 * sizeof(float));
+      const lk_result r = e->hs[s].last = fake_solve(e, e->hs[s], &e->guess[6 * s]);
+      e->hs[s].solved = true;
+      e->win_records[(size_t)f * S + s] = r;
+      std::memcpy(&e->last_p[6 * s], r.resultingParameters, 6 * sizeof(float));
+    }
+  }
+  e->sum[0] = keep_und, e->sum[1] = keep_def;
+  e->win_frames = n_frames;
+  e->win_outstanding = true;
+  J("correlate_sequence_async und_slot=%d first_slot=%d frames=%d ref_prev=%d cv=%d flags=%d", und_slot, first_slot, n_frames,
+    reference_previous, cv, flags);
+  return 0;
+}
+int lk_wait_sequence(lk_engine *e, lk_result *out) {
+  if (!e->win_outstanding)
+    return LK_ERROR_BAD_DOMAIN;
+  if (out)
+    std::memcpy(out, e->win_records.data(), e->win_records.size() * sizeof(lk_result));
+  e->win_outstanding = false;
+  return 0;
+}
+int lk_get_sequence_guesses(lk_engine *e, float *g) {
+  if (e->win_outstanding || e->win_guesses.empty())
+    return LK_ERROR_BAD_DOMAIN;
+  std::memcpy(g, e->win_guesses.data(), e->win_guesses.size() * sizeof(float));
   return 0;
 }
 int lk_wait_results(lk_engine *e, lk_result *out) {

@@ -248,3 +248,65 @@ def test_sharded_correlator_device_path_on_one_rank(speckle512):
     got = sc.correlate_all(np.zeros(6, np.float32))
     assert got.tobytes() == want.tobytes()
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["batch_invariant", "reference_order"])
+def test_group_windows_equal_one_engine_and_transfers_overlap_the_solve(mode):
+    """Three ranks on one device (the copy transport; every other line of code is the multi-GPU path): two
+    frame-pipelined windows of a sequence, the frames of window 1 enqueued while window 0 is being solved.
+    Records: the bytes of ONE engine solving the pairs one at a time.  Overlap: HIP event times on rank 1's device -
+    the transfer of window 1's frames begins after window 0's solve began and ends before it ended."""
+    K, n_ranks = 5, 3
+    frames = ca.speckle.speckle_sequence(640, 640, 2 * K + 1, velocity=(0.8, -0.4), dilation=2e-4, seed=5)
+    c, zero = (319.5, 319.5), np.zeros(6, np.float32)
+
+    def setup(obj, engines):
+        for fn in engines:
+            fn("lk_set_batch_invariant", 1) if mode == "batch_invariant" else fn("lk_set_reference_order", 1)
+
+    e = ca.HipCorrelationEngine()
+    setup(e, [lambda name, v: getattr(e.lib, name)(e._h, v)])
+    e.set_undeformed_image(frames[0])
+    e.set_rect_grid(24.0, 24.0, 615.0, 615.0, 66, 66)     # 7 x 7-sample sectors: two starved levels
+    e.commit_sectors()
+    want = []
+    for k in range(2 * K):
+        e.set_deformed_image(frames[k + 1])
+        e.adjust_initial_guess(k, True, zero, c)
+        want.append(e.correlate_all(None))
+    want = np.stack(want)
+    e.close()
+
+    g = ca.HipCorrelationGroup([0] * n_ranks)
+    setup(g, [g.for_each_engine])
+    g.set_image(ca.IMG_UND, frames[0])
+    g.set_rect_grid(24.0, 24.0, 615.0, 615.0, 66, 66)
+    g.commit_sectors()
+    g.sequence_reserve(2 * K)
+    g.sequence_set_frames(0, frames[1:K + 1])
+    g.adjust_initial_guess(0, True, zero, c)
+    g.correlate_sequence_async(K, first_slot=0)
+    g.sequence_set_frames(K, frames[K + 1:2 * K + 1])     # window 1's frames: behind window 0's solve, not behind the host
+    got0 = g.wait_sequence()
+    probe = g.probe_overlap(1)
+    g.adjust_initial_guess(K, True, zero, c)
+    g.correlate_sequence_async(K, first_slot=K)
+    got1 = g.wait_sequence()
+    got = np.concatenate([got0, got1])
+    assert got.shape == want.shape
+    for k in range(2 * K):
+        assert got[k].tobytes() == want[k].tobytes(), f"pair {k}"
+    assert probe[2] > 0 and probe[3] > 0, f"transfer {probe[0]:.3f} ms, solve {probe[1]:.3f} ms, begin offset {probe[2]:.3f}, end offset {probe[3]:.3f}"
+    # one pair at a time through the group, the next frame travelling behind the running solve (LK_IMG_NXT)
+    g.set_image(ca.IMG_DEF, frames[1])
+    g.adjust_initial_guess(0, True, zero, c)
+    g.correlate_all(None, fetch=False)
+    g.set_image(ca.IMG_NXT, frames[2])
+    probe = g.probe_overlap(2)
+    assert probe[2] > 0, "the next frame's transfer was enqueued behind the solve's begin, without a host wait"
+    g.rotate_def_from_nxt()
+    g.adjust_initial_guess(1, True, zero, c)
+    r1 = g.correlate_all(None)
+    assert r1.tobytes() == want[1].tobytes()
+    g.close()
