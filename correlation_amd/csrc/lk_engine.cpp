@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1564,6 +1565,40 @@ static int append_rect_sectors(lk_engine *e) {
     levels.push_back(l);
   // room for the new sectors (geometric growth; the committed part is kept)
   const size_t keep = (size_t)S0, want = (size_t)S1;
+  {
+    // A growth step reallocates: hipMalloc, a copy on the NULL stream, hipFree - none of which waits for the engine's
+    // (non-blocking) stream.  Append kernels, in-place patches or an unsynchronised solve (lk_correlate_all_device /
+    // _async) still queued there would write the old buffer behind the copy, and the hipFree would drop what they wrote.
+    // So the stream is drained first - only on the geometric growth steps, the O(1) path of the other commits is untouched.
+    bool grows = e->d_center.n < want || e->d_guess.n < 6 * want || e->d_last_p.n < 6 * want || e->d_prev_p.n < 6 * want ||
+                 e->d_last_eval_p.n < 6 * want || e->d_result.n < want || e->d_stats.n < 4 * want || e->d_handoff.n < want ||
+                 e->d_mid.n < want * kLkMidWords || e->d_ill_list.n < want || e->d_order.n < want || e->d_finish_list.n < want;
+    for (int l : levels)
+      grows = grows || e->d_rect[l].n < want || e->d_off[l].n < want + 1;
+    if (grows)
+      HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  // (a failure from here on leaves the host tables as they were and sends the next commit through the full rebuild)
+  const size_t rect0 = e->h_rect[0].size();
+  auto undo = [&, rect0]() {
+    for (int l : levels) {
+      if (e->h_rect[l].size() > rect0)
+        e->h_rect[l].resize(rect0);
+      if (e->h_off[l].size() > rect0 + 1)
+        e->h_off[l].resize(rect0 + 1);
+    }
+    e->h_center.resize(2 * keep);
+    e->h_class.resize(keep);
+    e->append_ok = false;
+  };
+  struct Guard {
+    std::function<void()> f;
+    bool armed = true;
+    ~Guard() {
+      if (armed)
+        f();
+    }
+  } guard{undo};
   HIPCHK(e->d_center.reserve_keep(want, keep));
   HIPCHK(e->d_guess.reserve_keep(6 * want, 6 * keep));
   HIPCHK(e->d_last_p.reserve_keep(6 * want, 6 * keep));
@@ -1626,6 +1661,7 @@ static int append_rect_sectors(lk_engine *e) {
       HIPCHK(e->d_finish_list.ensure(2 * want + 64));
     HIPCHK(e->d_finish_count.ensure(kNumClasses));
   }
+  guard.armed = false;
   e->S = S1;
   e->committed = true;
   e->classes_dirty = true; // the batch's size-class analysis and launch order: redone by the next batch solve

@@ -283,12 +283,15 @@ int collective_failed(lk_group *g, Member &me, int rc) {
 // fill stream, ordered by events: the host returns when everything is ENQUEUED.
 // which(member, i): the member's FrameBuf of frame i; src(i): its pixels (host, or rank 0's device);
 // fill(member, i, buf): hands the pixels to the member's engine (image slot or ring slot).
+// prefetch: the frames are not needed by the next solve (LK_IMG_NXT, ring slots of the next window) - they travel on the
+// communication stream, beside the running solve; frames the next solve reads (LK_IMG_UND / LK_IMG_DEF) stay in stream
+// order on the solve stream: nothing to overlap with, and every cross-stream hop costs a few microseconds.
 int distribute_frames(lk_group *g, Member &me, int n_frames, const std::function<FrameBuf &(Member &, int)> &which,
                       const std::function<const void *(int)> &src, bool on_device0, int rows, int cols, int step,
-                      const std::function<int(Member &, int, FrameBuf &)> &fill) {
+                      const std::function<int(Member &, int, FrameBuf &)> &fill, bool prefetch) {
   const size_t bytes = (size_t)rows * (size_t)cols;
   FrameBuf &f0 = which(me, 0);
-  hipStream_t cs = comm_stream(me);
+  hipStream_t cs = prefetch ? comm_stream(me) : me.st;
   const bool by_copy = g->loopback || g->copy_frames;
   int up = me.device_ok ? LK_ERROR_NONE : LK_ERROR_DEVICE;
   auto hip = [&](hipError_t he, const char *what, int &rc) {
@@ -534,7 +537,7 @@ static int set_image_any(lk_group *g, int slot, const void *src, bool on_device0
                                Member &me = q; // (GLK names `me`)
                                GLK(lk_internal_set_image_device_after(q.e, slot, fb.p, rows, cols, cols, fb.arrived, fb.consumed));
                                return LK_ERROR_NONE;
-                             });
+                             }, slot == LK_IMG_NXT);
   }, true);
 }
 int lk_group_set_image(lk_group *g, int slot, const uint8_t *host_pixels, int rows, int cols, int step) {
@@ -863,7 +866,7 @@ static int sequence_set_frames_any(lk_group *g, int first_slot, int n_frames, co
                                Member &me = q;
                                GLK(lk_internal_sequence_set_frame_device_after(q.e, first_slot + i, fb.p, rows, cols, cols, fb.arrived, fb.consumed));
                                return LK_ERROR_NONE;
-                             });
+                             }, true);
   }, true);
 }
 int lk_group_sequence_set_frames(lk_group *g, int first_slot, int n_frames, const uint8_t *const *host_pixels, int rows, int cols, int step) {

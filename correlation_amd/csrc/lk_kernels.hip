@@ -549,7 +549,9 @@ __device__ __forceinline__ bool evaluate(const LevelCtx &c, const float (&p)[6],
 #ifndef LK_PIPE_MIN_GROUP // lane groups at least this wide prefetch the next sample (tuning hook)
 #define LK_PIPE_MIN_GROUP 256
 #endif
-  if (GROUP >= LK_PIPE_MIN_GROUP && INTERP == LK_IM_BICUBIC && c.rw == 0) { // (explicit lists; implicit rectangles - config 1 - lose 6 % to it)
+  // (levels smaller than the 4 x 4 window - deep pyramids of small frames - take the plain loop: the branch-free prefetch
+  // below clamps its window INTO the image, which needs an image that holds one)
+  if (GROUP >= LK_PIPE_MIN_GROUP && INTERP == LK_IM_BICUBIC && c.rw == 0 && c.dcols >= 4 && c.drows >= 4) { // (explicit lists; implicit rectangles - config 1 - lose 6 % to it)
     // Software pipeline of the workgroup-wide groups (sectors of tens of thousands to millions of samples, explicit
     // lists, two wavefronts per SIMD): the list entry, the coordinates and the five image loads of sample k + stride
     // are issued before sample k's ~250 arithmetic instructions, so the two dependent load latencies of a trip
@@ -2231,7 +2233,8 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
 #ifdef LK_TRACE_FINE
     const unsigned long long tr_f0 = __builtin_amdgcn_s_memtime();
 #endif
-    if (phase == PH_FETCH && may_fetch) { // take the next sector
+    if (phase == PH_FETCH && may_fetch) // take the next sector
+     for (;;) { // (a drawn sector that needs nothing - finished by an earlier launch of the chain - is skipped here: draw again)
       int slot = 0;
       // (lists of parked sectors: their length is read BEFORE the ticket is drawn - see the rewind below)
       const int n_parked = (finisher || a.resume) ? (int)*(const volatile uint32_t *)a.finish_count : 0;
@@ -2325,6 +2328,9 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
         }
         if (k.level < a.py_start) {
           // finished by the starved-level kernel (result already written): take another
+          if (a.persistent && !STARVED)
+            continue;
+          phase = PH_EXIT; // (one sector per group by position: nothing else to take)
         } else if (STARVED && level_count(k.level, k.s) > a.starved_max) {
           hand_over(k); // nothing starved here: the lane-group kernel does it all
         } else {
@@ -2334,7 +2340,8 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
       } else {
         phase = PH_EXIT;
       }
-    }
+      break;
+     }
 #if defined(LK_TRACE_FINE) && !defined(LK_TRACE_TRANS)
     tr_fetch += __builtin_amdgcn_s_memtime() - tr_f0;
 #endif
@@ -2432,21 +2439,14 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
 #endif
     }
     if constexpr (GROUP >= kWave) {
-      if (!active) {
-        if (phase == PH_FETCH)
-          continue; // (the sector drawn needed nothing - finished by an earlier launch: draw again)
-        break;      // uniform over the workgroup: nothing left to do
-      }
+      if (!active)
+        break; // uniform over the workgroup: nothing left to do
     } else {
       const unsigned long long act = __ballot(active);
-      if (act == 0ull) {
-        // Rows still in PH_FETCH drew a sector that needed nothing (finished by an earlier launch): they fetch again.
-        // Leaving here instead is harmless for one wavefront - the others draw the remaining tickets - but when most
-        // sectors of a launch need nothing, every wavefront would leave within a few rounds and strand the rest.
-        if (__ballot(phase == PH_FETCH) != 0ull)
-          continue;
-        break; // every group of this wavefront is out of work
-      }
+      if (act == 0ull)
+        break; // every group of this wavefront is out of work (a group that drew a sector needing nothing drew again at once:
+               // a wavefront must not leave while tickets remain - when most sectors of a launch need nothing the others
+               // would not come to draw them)
       if constexpr (GROUP == 32) {
         // Solo: one half-wavefront is out of work for good (PH_EXIT) while its partner is still
         // solving - typically a sector that needs many more evaluations than its neighbour.

@@ -1910,6 +1910,77 @@ def test_sectors_appended_one_by_one_equal_the_full_commit(speckle512):
 
 
 @pytest.mark.gpu
+def test_appends_across_growth_steps_without_a_solve_or_a_synchronisation_in_between(speckle512):
+    """The append path grows the per-sector buffers geometrically (hipMalloc + copy + hipFree).  Kernels still queued on
+    the engine's non-blocking stream - the append kernels of the commits before, an unsynchronised solve - must not be
+    lost to such a step: 300 sectors committed one by one with nothing in between, then 100 more behind a solve that
+    nobody waited for, against ONE commit of the same rectangles."""
+    und, dfm = speckle512
+
+    def engine():
+        e = ca.HipCorrelationEngine()
+        e.set_batch_invariant(True)
+        e.set_undeformed_image(und)
+        e.set_deformed_image(dfm)
+        return e
+
+    rects = [(30 + 23 * (s % 19), 30 + 21 * (s // 19), 30 + 23 * (s % 19) + 12 + s % 5, 30 + 21 * (s // 19) + 14 - s % 3) for s in range(400)]
+    ref = engine()
+    for s, r in enumerate(rects):
+        ref.resetPolygon_rect(s, *r)
+    ref.commit_sectors()
+    want = ref.correlate_all(np.zeros(6, np.float32))
+    e = engine()
+    for s, r in enumerate(rects[:300]):                 # crosses several growth steps (64, 192, 448 ...), no solve, no sync
+        e.resetPolygon_rect(s, *r)
+        e.commit_sectors()
+    got300 = e.correlate_all(np.zeros(6, np.float32))
+    assert got300.tobytes() == want[:300].tobytes()
+    assert [e.sector_info(s) for s in (0, 63, 64, 191, 192, 299)] == [ref.sector_info(s) for s in (0, 63, 64, 191, 192, 299)]
+    e.adjust_initial_guess(0, False, np.zeros(6, np.float32), (255.5, 255.5))
+    e.correlate_all_device(0, 0)                        # an asynchronous solve into the engine's own record buffer ...
+    for s in range(300, 400):                           # ... and appends (with growth steps) right behind it
+        e.resetPolygon_rect(s, *rects[s])
+        e.commit_sectors()
+    e.synchronize()
+    # the unsynchronised solve's records survived the growth steps: sequence state of the first 300 sectors = want
+    e.adjust_initial_guess(1, False, np.zeros(6, np.float32), (255.5, 255.5))
+    g = e.get_guesses()
+    assert g[:300].tobytes() == np.ascontiguousarray(want["p"][:300]).tobytes() and not g[300:].any()
+    got = e.correlate_all(np.zeros(6, np.float32))
+    assert got.tobytes() == want.tobytes()
+    e.close()
+    ref.close()
+
+
+@pytest.mark.gpu
+def test_big_list_sector_on_a_small_frame_with_a_deep_pyramid():
+    """A workgroup-wide lane group on an explicit list walks the software-pipelined sample loop, whose branch-free
+    prefetch clamps its 4 x 4 window into the image - on pyramid levels smaller than 4 x 4 there is no such window and
+    the plain loop must take over (96 x 96 frame, six levels: 3 x 3 pixels at the top)."""
+    und, dfm = ca.speckle.speckle_pair(96, 96, p=(0.4, -0.3, 0.001, 0.0, 0.0, -0.001), seed=3)
+    ys, xs = np.mgrid[2:94, 2:94]
+    pts = np.stack([xs.T.ravel(), ys.T.ravel()], 1).astype(np.float32)      # 8464 samples: the 256-lane class, x outer / y inner
+    rec = {}
+    for kind in ("list", "rect"):
+        e = ca.HipCorrelationEngine(py_stop=5)
+        e.set_undeformed_image(und)
+        e.set_deformed_image(dfm)
+        if kind == "list":
+            e.set_sector_points(0, pts, center=(47.5, 47.5))
+        else:
+            e.resetPolygon_rect(0, 2, 2, 93, 93)
+        e.commit_sectors()
+        assert e.sector_level_count(0, 5) <= 9
+        rec[kind] = e.correlate_all(np.zeros(6, np.float32))[0]
+        e.close()
+    assert rec["list"]["n_points"] == rec["rect"]["n_points"] == 8464
+    assert rec["list"]["error_code"] == rec["rect"]["error_code"]
+    if rec["rect"]["error_code"] == 0:
+        assert np.abs(rec["list"]["p"] - rec["rect"]["p"])[:2].max() < 5e-3
+
+
+@pytest.mark.gpu
 def test_lists_from_the_host_get_a_row_major_evaluation_copy_too(oracle, monkeypatch):
     """lk_set_sector_points with lists in the reference's order (x outer / y inner): the commit sorts a copy of every
     such list by image row (stable counting sort) for the lane groups of the default mode, at every level - short lists
