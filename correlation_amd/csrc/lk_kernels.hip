@@ -2234,7 +2234,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
     const unsigned long long tr_f0 = __builtin_amdgcn_s_memtime();
 #endif
     if (phase == PH_FETCH && may_fetch) // take the next sector
-     for (;;) { // (a drawn sector that needs nothing - finished by an earlier launch of the chain - is skipped here: draw again)
+     for (;;) { // (drawn sectors that need nothing - finished by an earlier launch of the chain - are skipped here, see the end of the block)
       int slot = 0;
       // (lists of parked sectors: their length is read BEFORE the ticket is drawn - see the rewind below)
       const int n_parked = (finisher || a.resume) ? (int)*(const volatile uint32_t *)a.finish_count : 0;
@@ -2327,10 +2327,9 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
           k.level_old = 0;
         }
         if (k.level < a.py_start) {
-          // finished by the starved-level kernel (result already written): take another
-          if (a.persistent && !STARVED)
-            continue;
-          phase = PH_EXIT; // (one sector per group by position: nothing else to take)
+          // finished by the starved-level kernel (result already written): take another (below)
+          if (!a.persistent || STARVED)
+            phase = PH_EXIT; // (one sector per group by position: nothing else to take)
         } else if (STARVED && level_count(k.level, k.s) > a.starved_max) {
           hand_over(k); // nothing starved here: the lane-group kernel does it all
         } else {
@@ -2340,6 +2339,13 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
       } else {
         phase = PH_EXIT;
       }
+      // Every group that fetched here drew a sector that needs nothing: they draw again, TOGETHER - the groups of a wavefront
+      // keep drawing consecutive tickets, so that which sectors share a wavefront (adaptive width: the bits of the default
+      // mode) does not depend on timing.  A group that drew nothing while a neighbour got work sits this batch out.  No
+      // wavefront leaves while tickets remain: it leaves only once one of its groups has seen the end of the queue.
+      const bool all_drew_nothing = __ballot(phase != PH_FETCH) == 0ull; // (a statement of its own: every fetching lane takes part)
+      if (phase == PH_FETCH && all_drew_nothing)
+        continue;
       break;
      }
 #if defined(LK_TRACE_FINE) && !defined(LK_TRACE_TRANS)

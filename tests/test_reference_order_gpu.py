@@ -197,8 +197,9 @@ def test_default_mode_on_config4_sectors_stays_inside_the_reference_noise(oracle
     grid's NaN records - the sectors where a singular level decides between NaN parameters, max_iters and a
     result.  Measured (MI355X, round 3): 1 error code and 2 NaN flags of 3500 differ from oracle(T = 1), same
     iteration count on 93.0 % (the oracle's own T = 8 run: 89.0 %), |dp01| p50 7e-7 px, p99 0.061 px (T = 8: 1e-5,
-    0.070).  At the full 50 176 sectors the same thing shows as 7 differing error codes (bench.py,
-    other_configs.C4_one_pair.parity_vs_cpu).  Bounds: those numbers with margin, and never much worse than
+    0.070).  At the full 50 176 sectors the same thing shows as 17 differing error codes and 2 NaN flags (bench.py,
+    other_configs.C4_one_pair.parity_vs_cpu; bounded by tests/test_full_size_gpu.py::test_config4_default_mode_against_the_oracle_at_full_size).
+    Bounds: those numbers with margin, and never much worse than
     the reference's own thread-count noise."""
     w = wl.C4
     pair = ca.speckle.speckle_pair(w.size, w.size, p=w.truth, seed=7)
