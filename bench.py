@@ -962,12 +962,39 @@ def main():
                 for _ in range(n_e):
                     pair(two)
                 out_ms[label] = (time.perf_counter() - t0) / n_e * 1e3
+            # the reference's own loop shape (manager_class.cpp:1438-1447): while pair k is solved the next frame is loaded into the
+            # next-image slot, then def <- nxt by pointer rotation.  The frame sits in PINNED host memory (lk_pin_host_memory), so
+            # lk_set_image(LK_IMG_NXT) returns once the copy is enqueued on the next-frame stream: no helper thread - same host
+            # frames, same records copied back, synchronous per pair
+            import ctypes as C_
+            nxt = np.ascontiguousarray(dfm).copy()
+            pinned = ee.lib.lk_pin_host_memory(C_.c_void_p(nxt.ctypes.data), C_.c_size_t(nxt.nbytes)) == 0
+            ee.set_deformed_image(dfm)
+
+            def prefetched(n):
+                ee.set_next_image(nxt)
+                for _ in range(n):
+                    ee.correlate_all(g0)
+                    ee.makeDefPyramidFromNxt()
+                    ee.set_next_image(nxt)
+                ee.synchronize()
+
+            prefetched(3)
+            t0 = time.perf_counter()
+            prefetched(n_e)
+            out_ms["one_new_frame_prefetched"] = (time.perf_counter() - t0) / n_e * 1e3
+            ee.synchronize()
+            if pinned:
+                ee.lib.lk_unpin_host_memory(C_.c_void_p(nxt.ctypes.data))
             st_e = ee.stats()
             end_to_end = {"ms_per_pair": out_ms["two_new_frames"], "ms_per_pair_one_new_frame": out_ms["one_new_frame"],
+                          "ms_per_pair_one_new_frame_prefetched": out_ms["one_new_frame_prefetched"],
                           "point_iterations_per_s": st_e["point_iterations"] / (out_ms["two_new_frames"] * 1e-3),
                           "what": "host frames (pageable memory) -> lk_set_image upload + pyramids -> solve -> records copied back to "
                                   "the host, one pair at a time, synchronous (BASELINE.md 4.3); `one_new_frame`: the undeformed frame "
-                                  "stays (a sequence with a fixed reference).  Never the reported `value`."}
+                                  "stays (a sequence with a fixed reference); `_prefetched`: the same with the next frame - in pinned host memory "
+                                  "(lk_pin_host_memory) - uploaded into the next-image slot beside the running solve, def <- nxt by rotation: the "
+                                  "reference's frame loop (manager_class.cpp:1438-1447).  Never the reported `value`."}
             ee.close()
         except Exception as ex:   # noqa: BLE001
             end_to_end = {"error": repr(ex)}

@@ -62,6 +62,8 @@ SYMBOLS = {
     "lk_set_pairs_in_flight": (C.c_int, [_P, C.c_int]),
     "lk_synchronize": (C.c_int, [_P]),
     "lk_set_image": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
+    "lk_pin_host_memory": (C.c_int, [_P, C.c_size_t]),
+    "lk_unpin_host_memory": (C.c_int, [_P]),
     "lk_set_image_device": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "lk_set_image_pair_device": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "lk_rotate_und_from_def": (C.c_int, [_P]),
@@ -101,6 +103,7 @@ SYMBOLS = {
     "lk_wait_sequence": (C.c_int, [_P, _P]),
     "lk_get_sequence_results_device": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "lk_sequence_is_pipelined": (C.c_int, [_P]),
+    "lk_sequence_host_records": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
     "lk_copy_sequence_records_device": (C.c_int, [_P, _P, C.c_size_t]),
     "lk_get_sequence_guesses": (C.c_int, [_P, _F]),
     "lk_adjust_initial_guess": (C.c_int, [_P, C.c_int, C.c_int, _F, C.c_float, C.c_float]),

@@ -297,8 +297,9 @@ struct lk_engine {
     bool pipelined = false, outstanding = false;
   } seq;
   uint32_t *h_seq_flags = nullptr;      // pinned [4]
-  lk_result *h_seq_results = nullptr;   // pinned [frames][S]
-  size_t h_seq_results_n = 0;
+  lk_result *h_seq_results[2] = {nullptr, nullptr}; // pinned [frames][S], alternating by window: the caller may digest window w's
+  size_t h_seq_results_n[2] = {0, 0};               //   records (lk_sequence_host_records) while window w + 1 is being solved
+  int h_seq_cur = 0;                                // buffer of the window launched last
   hipEvent_t ev_seq = nullptr;
   int stats_frames = 1;                 // frames the counters of the last solve cover (a window: its frames)
   lk_result *h_results = nullptr; // pinned: where lk_correlate_all_async leaves the records
@@ -436,8 +437,9 @@ void lk_destroy(lk_engine *e) {
   e->d_prev_p_alt.release();
   if (e->h_seq_flags)
     (void)hipHostFree(e->h_seq_flags);
-  if (e->h_seq_results)
-    (void)hipHostFree(e->h_seq_results);
+  for (lk_result *hp : e->h_seq_results)
+    if (hp)
+      (void)hipHostFree(hp);
   for (hipStream_t cs : e->class_stream)
     if (cs)
       (void)hipStreamDestroy(cs);
@@ -546,6 +548,18 @@ static int prepare_slot(lk_engine *e, DevImage &im, int rows, int cols, hipStrea
   return LK_ERROR_NONE;
 }
 
+// Is a host pointer pinned (hipHostMalloc / hipHostRegister: lk_pin_host_memory)?  A copy from pinned memory is a DMA the
+// stream orders; from pageable memory the runtime stages it, and the caller's buffer is only safe once the stream has
+// passed the copy.
+static bool host_pinned(const void *p) {
+  hipPointerAttribute_t a{};
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError(); // (pageable memory: not an error of ours)
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
 // upload (or device copy) of one frame into `im` + its pyramid levels, on stream `st`
 static int fill_image(lk_engine *e, DevImage &im, const void *src, bool src_on_device, int rows, int cols, int step,
                       hipStream_t st, bool timed) {
@@ -624,9 +638,20 @@ static int set_image_common(lk_engine *e, int slot, const void *src, bool src_on
   } else {
     e->lv_dirty = true;
   }
-  if (!src_on_device) // pageable host memory: the copy must have left it
+  if (!src_on_device && !host_pinned(src)) // pageable host memory: the copy must have left it
     HIPCHK(hipStreamSynchronize(st));
   return LK_ERROR_NONE;
+}
+
+int lk_pin_host_memory(void *ptr, size_t bytes) {
+  if (!ptr || !bytes)
+    return LK_ERROR_BAD_DOMAIN;
+  return hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess ? LK_ERROR_NONE : LK_ERROR_DEVICE;
+}
+int lk_unpin_host_memory(void *ptr) {
+  if (!ptr)
+    return LK_ERROR_BAD_DOMAIN;
+  return hipHostUnregister(ptr) == hipSuccess ? LK_ERROR_NONE : LK_ERROR_DEVICE;
 }
 
 int lk_set_image(lk_engine *e, int slot, const uint8_t *host_pixels, int rows, int cols, int step) {
@@ -2810,7 +2835,7 @@ static int sequence_set_frame(lk_engine *e, int slot, const void *src, bool on_d
   HIPCHK(hipEventRecord(e->ring_ready[(size_t)slot], st));
   e->ring_fresh[(size_t)slot] = 1;
   lock.unlock();
-  if (!on_device) // pageable host memory: the copy must have left it
+  if (!on_device && !host_pinned(src)) // pageable host memory: the copy must have left it
     HIPCHK(hipStreamSynchronize(st));
   return LK_ERROR_NONE;
 }
@@ -2837,8 +2862,20 @@ static int seq_group_of_class(const lk_engine *e, int c, int n) {
   const int g = kGroupOfClass[c];
   if (g > 64)
     return -1;
-  if (e->class_starved[c] && g != 16) // (starved levels inside the window: the 16-lane rows' finisher arithmetic)
-    return -1;
+  if (e->class_starved[c]) {
+    if (g != 16) // (starved levels inside the window: the 16-lane rows' finisher arithmetic)
+      return -1;
+    // ... which pays while the sectors are small.  Config 5's geometry (17 x 17 samples, one starved level of four) measured
+    // 9.1 ms per pair in a window against 5.9 (default) / 7.4 (batch-invariant) for the one-pair chain, whose one-lane kernel
+    // shares one instruction stream of the QR among 64 sectors and whose lane groups widen: such classes keep the chain, frame
+    // after frame.  9 x 9 samples: 1.12 against 1.66; 7 x 7: 0.98-1.21 against 1.6-1.9.
+    static const int big_n0 = [] { const char *f = std::getenv("LK_SEQ_STARVED_MAX_N0"); return f ? std::atoi(f) : 128; }(); // tuning hook
+    long long n0 = 0;
+    for (int i = e->class_begin[c]; i < e->class_begin[c + 1]; ++i)
+      n0 += level0_count(e, (int)e->h_order[(size_t)i]);
+    if (n0 > (long long)big_n0 * n)
+      return -1;
+  }
   return g;
 }
 
@@ -2991,7 +3028,7 @@ static int launch_window(lk_engine *e, bool force_safe_flavour) {
     e->solve_timed = true;
   }
   if (w.want_host)
-    HIPCHK(hipMemcpyAsync(e->h_seq_results, e->d_seq_result.p, (size_t)n * (size_t)S * sizeof(lk_result), hipMemcpyDeviceToHost,
+    HIPCHK(hipMemcpyAsync(e->h_seq_results[e->h_seq_cur], e->d_seq_result.p, (size_t)n * (size_t)S * sizeof(lk_result), hipMemcpyDeviceToHost,
                           e->stream));
   HIPCHK(hipEventRecord(e->ev_seq, e->stream));
   e->stats_valid = false;
@@ -3072,13 +3109,17 @@ int lk_correlate_sequence_async(lk_engine *e, int und_slot, int first_slot, int 
   if (!e->h_seq_flags)
     HIPCHK(hipHostMalloc((void **)&e->h_seq_flags, 4 * sizeof(uint32_t), hipHostMallocDefault));
   std::memset(e->h_seq_flags, 0, 4 * sizeof(uint32_t));
-  if (w.want_host && e->h_seq_results_n < (size_t)n_frames * (size_t)S) {
-    if (e->h_seq_results)
-      HIPCHK(hipHostFree(e->h_seq_results));
-    e->h_seq_results = nullptr;
-    e->h_seq_results_n = 0;
-    HIPCHK(hipHostMalloc((void **)&e->h_seq_results, (size_t)n_frames * (size_t)S * sizeof(lk_result), hipHostMallocDefault));
-    e->h_seq_results_n = (size_t)n_frames * (size_t)S;
+  if (w.want_host) {
+    e->h_seq_cur ^= 1;
+    const int b = e->h_seq_cur;
+    if (e->h_seq_results_n[b] < (size_t)n_frames * (size_t)S) {
+      if (e->h_seq_results[b])
+        HIPCHK(hipHostFree(e->h_seq_results[b]));
+      e->h_seq_results[b] = nullptr;
+      e->h_seq_results_n[b] = 0;
+      HIPCHK(hipHostMalloc((void **)&e->h_seq_results[b], (size_t)n_frames * (size_t)S * sizeof(lk_result), hipHostMallocDefault));
+      e->h_seq_results_n[b] = (size_t)n_frames * (size_t)S;
+    }
   }
   if (!e->ev_seq)
     HIPCHK(hipEventCreateWithFlags(&e->ev_seq, hipEventDisableTiming));
@@ -3148,7 +3189,16 @@ int lk_wait_sequence(lk_engine *e, lk_result *out) {
                           hipMemcpyDeviceToDevice, e->stream));
   }
   if (out)
-    std::memcpy(out, e->h_seq_results, (size_t)n * (size_t)S * sizeof(lk_result));
+    std::memcpy(out, e->h_seq_results[e->h_seq_cur], (size_t)n * (size_t)S * sizeof(lk_result));
+  return LK_ERROR_NONE;
+}
+
+int lk_sequence_host_records(lk_engine *e, const lk_result **records) {
+  if (!e || !records)
+    return LK_ERROR_BAD_DOMAIN;
+  if (e->seq.outstanding || !e->seq.want_host || !e->h_seq_results[e->h_seq_cur])
+    return e->fail(LK_ERROR_BAD_DOMAIN, "lk_sequence_host_records: no waited-for window with host records (flags & 1)");
+  *records = e->h_seq_results[e->h_seq_cur];
   return LK_ERROR_NONE;
 }
 

@@ -931,7 +931,7 @@ int lk_sequence_run(lk_engine *e, lk_tracker *t, int n_frames, lk_frame_provider
     rc = lk_tracker_begin_frame(t, 0, cmds.data(), guesses.data());
     if (!rc)
       rc = register_sectors(e, t, cmds);
-    // Windows of K pairs (LK_SEQ_WINDOW, default 32; 1 = pair by pair, below): the K deformed frames of a window are
+    // Windows of K pairs (LK_SEQ_WINDOW, default 16; 1 = pair by pair, below): the K deformed frames of a window are
     // resident in the engine's ring and ONE launch per size class solves them all, every sector moving on to its next
     // frame as soon as its own previous frame is done (lk_correlate_sequence_async) - the guess of pair k + 1 needs
     // nothing but the sector's own earlier results (manager_class.cpp:2677-2699).  While window w is being solved a helper
@@ -940,7 +940,7 @@ int lk_sequence_run(lk_engine *e, lk_tracker *t, int n_frames, lk_frame_provider
     // on this thread.  Same records, same report text as the pair-by-pair loop in batch-invariant and reference-order
     // mode (tests/test_sequence_window_gpu.py).
     const char *win_env = std::getenv("LK_SEQ_WINDOW");
-    const int K = std::min(pairs, win_env ? std::max(1, std::atoi(win_env)) : 32);
+    const int K = std::min(pairs, win_env ? std::max(1, std::atoi(win_env)) : 16);
     if (!rc && K >= 2) {
       const int R = 2 * K;
       rc = lk_sequence_reserve(e, R);
@@ -958,10 +958,10 @@ int lk_sequence_run(lk_engine *e, lk_tracker *t, int n_frames, lk_frame_provider
       };
       for (int f = 2; f <= K && !rc; ++f)
         rc = upload(f);
-      std::vector<lk_result> win[2];
+      // (the records of a window stay where the engine's copy left them: its pinned host buffers alternate, so window w's are
+      // still there while window w + 1 is solved - and gone when window w + 2 is launched: the bookkeeping of w runs before that)
+      const lk_result *win[2] = {nullptr, nullptr};
       std::vector<float> win_guess[2], win_first[2]; // check mode: the guesses the device solved from (first frame: the guess kernel's)
-      win[0].resize((size_t)K * (size_t)S);
-      win[1].resize((size_t)K * (size_t)S);
       if (check)
         for (int b = 0; b < 2; ++b) {
           win_guess[b].resize((size_t)K * 6 * (size_t)S);
@@ -983,7 +983,7 @@ int lk_sequence_run(lk_engine *e, lk_tracker *t, int n_frames, lk_frame_provider
           }
           int first_unsolved = S, stop = 0; // (never a stop: the continue policy is a condition of this path)
           if (!r)
-            r = lk_tracker_end_frame(t, k, und_k.c_str(), frame_name[(size_t)k + 1].c_str(), win[have_buf].data() + (size_t)i * (size_t)S,
+            r = lk_tracker_end_frame(t, k, und_k.c_str(), frame_name[(size_t)k + 1].c_str(), win[have_buf] + (size_t)i * (size_t)S,
                                      &first_unsolved, &stop);
           if (!r && pairs_done)
             *pairs_done = k + 1;
@@ -1020,9 +1020,11 @@ int lk_sequence_run(lk_engine *e, lk_tracker *t, int n_frames, lk_frame_provider
         if (!rc && have_n > 0) // the window before: its bookkeeping runs behind the solve just launched
           rc = bookkeeping();
         if (launched) {
-          const int wrc = lk_wait_sequence(e, rc ? nullptr : win[buf].data());
+          const int wrc = lk_wait_sequence(e, nullptr);
           if (!rc)
             rc = wrc;
+          if (!rc)
+            rc = lk_sequence_host_records(e, &win[buf]);
         }
         if (!rc && check)
           rc = lk_get_sequence_guesses(e, win_guess[buf].data());

@@ -154,6 +154,14 @@ int lk_synchronize(lk_engine *e);
  * level-0 pixels (monochrome u8, `step` bytes per row) and build levels 1..py_stop.
  * File decoding stays with the caller. */
 int lk_set_image(lk_engine *e, int slot, const uint8_t *host_pixels, int rows, int cols, int step);
+/* Frames in PINNED host memory ("pinned staging + hipMemcpyAsync on a dedicated stream"; the reference uploads
+ * from pageable cv::Mat pixels, cuda_pyramid.cu:83-103).  lk_pin_host_memory page-locks a caller's frame buffer
+ * (hipHostRegister; hipHostMalloc'ed memory needs nothing).  lk_set_image / lk_sequence_set_frame from pinned memory
+ * return as soon as the copy is ENQUEUED - with LK_IMG_NXT or a ring slot on the next-frame stream, i.e. beside a running
+ * solve, without a helper thread - instead of waiting for it as they do for pageable memory.  The buffer must stay
+ * unchanged until the frame has been used: until the next lk_correlate_* that reads it has returned, or lk_synchronize. */
+int lk_pin_host_memory(void *ptr, size_t bytes);
+int lk_unpin_host_memory(void *ptr);
 /* same, pixels already in this device's memory (used after an RCCL broadcast) */
 int lk_set_image_device(lk_engine *e, int slot, const void *device_pixels, int rows, int cols, int step);
 /* CudaClass::resetImagePyramids(und, def, ...) (cuda_class.cu:475-519): both frames of a pair,
@@ -290,8 +298,9 @@ int lk_wait_results(lk_engine *e, lk_result *out);
  * mode the window's records are byte-identical to solving the pairs one after the other with
  * lk_adjust_initial_guess + lk_correlate_all*.  The default mode uses the fixed lane groups and the fast flavour
  * inside a window (a window in which a damped system meets a bad pivot is solved again with the SAFE flavour).
- * Domains with sectors of more than 8192 samples (workgroup-wide groups, teams) have no pipelined instance:
- * their windows run the frames one after the other on the device - same interface, same records. */
+ * Domains with sectors of more than 8192 samples (workgroup-wide groups, teams), and classes of more than 128 samples per
+ * sector that have a starved pyramid level (config 5's geometry: their one-pair launch chain is the faster form), have
+ * no pipelined instance: their windows run the frames one after the other on the device - same interface, same records. */
 /* a ring of n_slots resident deformed-frame pyramids (grows; never shrinks) */
 int lk_sequence_reserve(lk_engine *e, int n_slots);
 /* upload + pyramid of one frame into ring slot `slot`, on the next-frame stream: may overlap a running
@@ -311,6 +320,10 @@ int lk_correlate_sequence_async(lk_engine *e, int und_slot, int first_slot, int 
 /* block until the window is solved; out: [n_frames][S] records (frame-major) or NULL.  LK_ERROR_DEVICE if the
  * window is void (a bounded wait inside the kernel gave up: cannot happen unless the device loses wavefronts). */
 int lk_wait_sequence(lk_engine *e, lk_result *out);
+/* (flags & 1) the waited-for window's records [n_frames][S] in the engine's own pinned host memory - no copy; two buffers
+ * alternate, so the pointer stays valid while the NEXT window is launched and solved (until the launch after that): a
+ * frame loop digests window w while window w + 1 runs (lk_sequence_run) */
+int lk_sequence_host_records(lk_engine *e, const lk_result **records);
 /* the window's records [n_frames][S] and (flags & 2) guesses [n_frames][S][6] in device memory */
 int lk_get_sequence_results_device(lk_engine *e, const void **d_records, const void **d_guesses);
 /* the last window's records into a caller's device buffer, frame f at d_dst + f * dst_pitch_records records

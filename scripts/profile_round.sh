@@ -74,6 +74,15 @@ if [ -f build/tune/liblk_trace_ord_fine.so ]; then   # ... -DLK_TRACE_FINE: cycl
   LK_REF_ORDER=1 LK_ENGINE_LIB=$PWD/build/tune/liblk_trace_ord_fine.so timeout -k 10 120 python3 scripts/trace_solve.py "$out/trace_c2_ord_fine.npz" > /dev/null 2>&1 &&
     { python3 scripts/trace_fine.py "$out/trace_c2_ord_fine.npz"; python3 scripts/trace_top.py "$out/trace_c2_ord_fine.npz" 8; } >> "$out/${tag}_reforder_wave_timeline.txt" 2>&1
 fi
+python3 - "$out/${tag}_traffic.json" "$out/${tag}_wave_timeline.txt" <<'PY'
+import json, os, re, sys
+d = json.load(open(sys.argv[1]))
+if os.path.exists(sys.argv[2]):
+    c = re.search(r"clock ([0-9.]+) GHz", open(sys.argv[2]).read())
+    if c:
+        d.setdefault("measured_clock_GHz", {})["one_pair_C2"] = float(c.group(1))
+json.dump(d, open(sys.argv[1], "w"), indent=1)
+PY
 # the one-rank rehearsal of the multi-process bench (RCCL in the loop, every block of the N > 1 line)
 LK_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout -k 10 400 python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-other-configs > "$out/${tag}_bench_dist_rehearsal.json" 2> "$out/bench_dist.err"
 rm -rf "$out/c4" "$out"/pmc*/ "$out/trace" "$out"/*.npz

@@ -24,7 +24,7 @@ for cfg in "C2 default" "C2 reference_order" "C4 default" "C4 batch_invariant"; 
     i=$((i + 1))
     LK_MODE=$2 LK_SEQ_LOOP=0 timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d "$out/pmc$i" -o pmc -- python3 scripts/quick_sequence.py $1 64 1 > "$out/spmc.log" 2>&1 || echo "pass $i ($set) of $cfg failed" >> "$out/progress.log"
   done
-  python3 scripts/summarize_pmc.py "$out" "$tag: window of 64 pairs, $1, LK_MODE=$2 (scripts/quick_sequence.py $1 64 1: three launches of the window kernel)" | grep -v "^units\|lk_pyramid\|lk_guess\|lk_set_views\|lk_stale" >> "$out/${tag}_seq_pmc.txt"
+  python3 scripts/summarize_pmc.py "$out" "$tag: window of 64 pairs, $1, LK_MODE=$2 (scripts/quick_sequence.py $1 64 1: three launches of the window kernel)" | sed 's/ on `python3 scripts\/quick_solve.py C2 5`, MI355X,//' | grep -v "^units\|lk_pyramid\|lk_guess\|lk_set_views\|lk_stale" >> "$out/${tag}_seq_pmc.txt"
   rm -rf "$out"/pmc*/
   echo "pmc $cfg done" >> "$out/progress.log"
 done
@@ -32,4 +32,32 @@ for lib in build/tune/liblk_trace_seq32.so:C2:default build/tune/liblk_trace_seq
   IFS=: read -r so wl mode <<< "$lib"
   [ -f "$so" ] && LK_MODE=$mode LK_ENGINE_LIB=$PWD/$so timeout -k 10 200 python3 scripts/trace_sequence.py $wl 64 2>&1 | grep -v amdgpu.ids >> "$out/${tag}_seq_wave_timeline.txt" && echo >> "$out/${tag}_seq_wave_timeline.txt"
 done
+# the windows' per-pair constants into <tag>_traffic.json (beside the one-pair constants of scripts/profile_round.sh, if that ran first)
+python3 - "$out/${tag}_seq_pmc.txt" "$out/${tag}_traffic.json" "$out/${tag}_seq_wave_timeline.txt" "$tag" <<'PY'
+import json, os, re, sys
+pmc, dst, timeline, tag = sys.argv[1:5]
+d = json.load(open(dst)) if os.path.exists(dst) else {}
+valu, hbm = {}, {}
+for b in re.split(r"rocprofv3 --pmc passes", open(pmc).read())[1:]:
+    m = re.search(r"window of 64 pairs, (\w+), LK_MODE=(\w+)", b)
+    vals = {mm.group(1): float(mm.group(2)) for mm in re.finditer(r"> (\w+)\s+dispatches=\d+ mean=([0-9.e+]+)", b)}
+    if m and "SQ_INSTS_VALU" in vals:
+        key = f"{m.group(1)}_{m.group(2)}"
+        valu[key] = vals["SQ_INSTS_VALU"] / 64
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            hbm[key] = (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 / 64
+d["valu_insts_per_window_pair"] = dict(valu, source=f"profiles/{tag}_seq_pmc.txt: SQ_INSTS_VALU of one 64-pair window launch / 64")
+d["hbm_bytes_per_window_pair"] = dict(hbm, source=f"profiles/{tag}_seq_pmc.txt: (FETCH_SIZE + WRITE_SIZE) KiB of one 64-pair window launch / 64")
+clk = d.get("measured_clock_GHz", {"one_pair_C2": 2.07})
+if os.path.exists(timeline):
+    for blk in open(timeline).read().split("\n\n"):
+        m = re.match(r"(C\w+):", blk.strip())
+        mm = re.search(r"mode (\w+):", blk)
+        c = re.search(r"clock ([0-9.]+) GHz", blk)
+        if m and mm and c:
+            clk[f"window_{m.group(1)}_{mm.group(1)}"] = float(c.group(1))
+clk["source"] = f"profiles/{tag}_seq_wave_timeline.txt, profiles/*_wave_timeline.txt: shader cycles / device time of the traced wavefronts"
+d["measured_clock_GHz"] = clk
+json.dump(d, open(dst, "w"), indent=1)
+PY
 cat "$out/${tag}_seq_pmc.txt"; cat "$out/${tag}_seq_wave_timeline.txt"

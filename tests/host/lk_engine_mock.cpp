@@ -36,7 +36,8 @@ struct lk_engine {
   // frame-pipelined windows: the ring holds the image checksums; a window is the loop of one-pair solves
   std::vector<unsigned> ring_sum;
   std::vector<char> ring_valid;
-  std::vector<lk_result> win_records;
+  std::vector<lk_result> win_records, win_records_kept[2];
+  int win_kept = 0;
   std::vector<float> win_guesses;
   int win_frames = 0;
   bool win_outstanding = false;
@@ -398,6 +399,13 @@ int lk_wait_sequence(lk_engine *e, lk_result *out) {
   if (out)
     std::memcpy(out, e->win_records.data(), e->win_records.size() * sizeof(lk_result));
   e->win_outstanding = false;
+  return 0;
+}
+int lk_sequence_host_records(lk_engine *e, const lk_result **records) {
+  if (e->win_outstanding || e->win_records.empty())
+    return LK_ERROR_BAD_DOMAIN;
+  e->win_records_kept[e->win_kept ^= 1] = e->win_records; // (two alternating buffers, like the engine's pinned ones)
+  *records = e->win_records_kept[e->win_kept].data();
   return 0;
 }
 int lk_get_sequence_guesses(lk_engine *e, float *g) {

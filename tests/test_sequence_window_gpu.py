@@ -226,3 +226,36 @@ def full_size_frames(n):
     if len(_FULL.get("frames", ())) < n:
         _FULL["frames"] = ca.speckle.speckle_sequence(2048, 2048, n, velocity=(0.8, -0.4), dilation=1e-4, seed=7, device="cuda")
     return _FULL["frames"]
+
+
+def test_frames_from_pinned_host_memory_upload_without_waiting(frames448):
+    """lk_pin_host_memory: image slots, the next-image slot and ring slots filled from page-locked frames (the call
+    returns when the copy is enqueued) give the records of the same frames from pageable memory"""
+    import ctypes as C
+    frames = frames448
+    pinned = [np.ascontiguousarray(f).copy() for f in frames[:4]]
+    a, b = make_engine("batch_invariant"), make_engine("batch_invariant")
+    for f in pinned:
+        assert b.lib.lk_pin_host_memory(C.c_void_p(f.ctypes.data), C.c_size_t(f.nbytes)) == 0
+    for e, src in ((a, frames), (b, pinned)):
+        e.set_undeformed_image(src[0])
+        e.set_deformed_image(src[1])
+        domain(e, "c2like", 448)
+    want1, got1 = a.correlate_all(ZERO), b.correlate_all(ZERO)
+    assert got1.tobytes() == want1.tobytes()
+    for e, src in ((a, frames), (b, pinned)):
+        e.set_next_image(src[2])
+        e.makeDefPyramidFromNxt()
+    want2, got2 = a.correlate_all(ZERO), b.correlate_all(ZERO)
+    assert got2.tobytes() == want2.tobytes() and got2.tobytes() != got1.tobytes()
+    for e, src in ((a, frames), (b, pinned)):
+        e.sequence_reserve(3)
+        for i in range(3):
+            e.sequence_set_frame(i, src[i + 1])
+        e.adjust_initial_guess(0, True, ZERO, (223.5, 223.5))
+    assert a.correlate_sequence(3).tobytes() == b.correlate_sequence(3).tobytes()
+    b.synchronize()
+    for f in pinned:
+        assert b.lib.lk_unpin_host_memory(C.c_void_p(f.ctypes.data)) == 0
+    a.close()
+    b.close()
