@@ -971,10 +971,13 @@ def main():
             pinned = ee.lib.lk_pin_host_memory(C_.c_void_p(nxt.ctypes.data), C_.c_size_t(nxt.nbytes)) == 0
             ee.set_deformed_image(dfm)
 
+            ee.adjust_initial_guess(0, False, g0, (wl.size / 2.0, wl.size / 2.0))   # the engine-held (zero) guesses, once
+
             def prefetched(n):
                 ee.set_next_image(nxt)
                 for _ in range(n):
-                    ee.correlate_all(g0)
+                    ee.correlate_all_async()          # the engine-held guesses; records follow the solve into pinned memory
+                    ee.wait_results()                 # ... and are copied out
                     ee.makeDefPyramidFromNxt()
                     ee.set_next_image(nxt)
                 ee.synchronize()

@@ -19,6 +19,7 @@
 #include <rocprofiler-sdk-roctx/roctx.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -2579,6 +2580,21 @@ int lk_correlate_all_async(lk_engine *e) {
   return LK_ERROR_NONE;
 }
 
+// Wait for an event with the latency of a polling loop: hipEventSynchronize may put the thread to sleep and wake it
+// hundreds of microseconds late - more than a whole C2 solve takes.  Poll for a while first (a solve is 0.2-10 ms), then
+// block.
+static hipError_t wait_event(hipEvent_t ev) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipEventQuery(ev);
+    if (q != hipErrorNotReady)
+      return q;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
+      return hipEventSynchronize(ev);
+    std::this_thread::yield();
+  }
+}
+
 int lk_wait_results(lk_engine *e, lk_result *out) {
   Range range_("lk:gather records");
   if (!e)
@@ -2586,7 +2602,7 @@ int lk_wait_results(lk_engine *e, lk_result *out) {
   if (!e->results_pending || !out)
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_wait_results: no solve outstanding / null buffer");
   HIPCHK(hipSetDevice(e->cfg.device));
-  HIPCHK(hipEventSynchronize(e->ev_results));
+  HIPCHK(wait_event(e->ev_results));
   e->results_pending = false;
   std::memcpy(out, e->h_results, (size_t)e->S * sizeof(lk_result));
   return LK_ERROR_NONE;
@@ -2870,10 +2886,18 @@ static int seq_group_of_class(const lk_engine *e, int c, int n) {
     // shares one instruction stream of the QR among 64 sectors and whose lane groups widen: such classes keep the chain, frame
     // after frame.  9 x 9 samples: 1.12 against 1.66; 7 x 7: 0.98-1.21 against 1.6-1.9.
     static const int big_n0 = [] { const char *f = std::getenv("LK_SEQ_STARVED_MAX_N0"); return f ? std::atoi(f) : 128; }(); // tuning hook
-    long long n0 = 0;
-    for (int i = e->class_begin[c]; i < e->class_begin[c + 1]; ++i)
-      n0 += level0_count(e, (int)e->h_order[(size_t)i]);
-    if (n0 > (long long)big_n0 * n)
+    long long n0 = 0, n_starved = 0; // (over the sectors that HAVE a starved level: a class may mix them with others)
+    const int top = e->cfg.py_stop;
+    for (int i = e->class_begin[c]; i < e->class_begin[c + 1]; ++i) {
+      const int s = (int)e->h_order[(size_t)i];
+      const int4 r = e->h_rect[top][(size_t)s];
+      const int n_top = r.z > 0 ? r.w : (int)(e->h_off[top][(size_t)s + 1] - e->h_off[top][(size_t)s]);
+      if (n_top <= starved_max(e)) {
+        n0 += level0_count(e, s);
+        ++n_starved;
+      }
+    }
+    if (n0 > (long long)big_n0 * n_starved)
       return -1;
   }
   return g;
@@ -3160,7 +3184,7 @@ int lk_wait_sequence(lk_engine *e, lk_result *out) {
   if (out && !w.want_host)
     return e->fail(LK_ERROR_BAD_DOMAIN, "lk_wait_sequence: the window was launched without host records (flags & 1)");
   HIPCHK(hipSetDevice(e->cfg.device));
-  HIPCHK(hipEventSynchronize(e->ev_seq));
+  HIPCHK(wait_event(e->ev_seq));
   w.outstanding = false;
   const int S = e->S, n = w.n_frames;
   if (w.pipelined) {

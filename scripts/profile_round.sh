@@ -48,8 +48,8 @@ def means(path, kernel):
     return out
 
 
-d = means(sys.argv[1], "lk_solve_kernel<3, 2, 32, 64, false, false>")
-r = means(sys.argv[2], "lk_solve_kernel<3, 2, 16, 64, true, true>")
+d = means(sys.argv[1], "lk_solve_kernel<3, 2, 32, 64, false, false, false>")
+r = means(sys.argv[2], "lk_solve_kernel<3, 2, 16, 64, true, true, false>")
 tag = sys.argv[3]
 print(json.dumps({
     "solve_kernel_hbm_bytes_per_launch_C2": (d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0,
