@@ -1101,7 +1101,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl.name, "sectors_per_gpu": S, "sectors_total": wl.hs * wl.vs if strong else S * world,
                        "samples_per_sector": n0,
-                       "interpolation": "bicubic", "parallelism": f"sectors sharded x{world}",
+                       "interpolation": "bicubic",
+                       "parallelism": (f"sector grid sharded x{world} (strong scaling)" if strong else
+                                       (f"WEAK scaling x{world}: every rank correlates its own {S}-sector grid on the broadcast pair (the work grows "
+                                        "with N); the strong-scaling runs - ONE grid / ONE sequence split over the ranks - are "
+                                        "`sharded_configs`" if world > 1 else "one GPU")),
                        "pairs_in_flight": P,
                        "step": "pyramid(und)+pyramid(def)+solve of one pair, inputs resident in HBM, "
                                + ("one pair at a time" if P == 1 else f"up to {P} independent pairs overlap on the GPU")},

@@ -13,6 +13,27 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NUM = (int, float)
 
 
+def check_sequence_blocks(d, n1):
+    """round 4: tracked sequences - frame-pipelined windows against the one-pair loop (N = 1) and sharded over the ranks"""
+    for key in ("C4_sequence", "C2_sequence"):
+        s = d["sharded_configs"][key]
+        assert "error" not in s, s
+        assert s["n_ranks"] == d["n_ranks"] and s["scaling"] == "strong" and s["pairs"] >= 2 and s["window_pairs"] >= 1
+        assert s["ms_per_pair"] > 0 and abs(s["speedup_vs_1gpu"] - s["ms_per_pair_1gpu"] / s["ms_per_pair"]) < 1e-9
+    if n1:
+        for cfg in ("C2", "C4"):
+            for mode in ("default", "reference_order"):
+                b = d["sequence"][cfg][mode]
+                assert "error" not in b, b
+                w = b["window"]
+                assert b["pipelined_instances"] is True and w["kernel_ms_per_pair"] > 0 and w["ms_per_pair"] >= w["kernel_ms_per_pair"]
+                assert abs(w["frac"] - w["algorithmic_bytes_per_pair"] / (w["kernel_ms_per_pair"] * 1e-3) / 1e9 / 8000.0) < 1e-9
+                assert w["speedup_vs_one_pair_at_a_time"] > 1.0
+            ro = d["sequence"][cfg]["reference_order"]["one_pair_at_a_time"]
+            assert ro["frames_with_identical_records"] == ro["of"] == d["sequence"][cfg]["reference_order"]["pairs"]
+        assert d["end_to_end"]["ms_per_pair_one_new_frame_prefetched"] > 0
+
+
 def check_line(d, n1):
     for k, t in (("metric", str), ("value", NUM), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                  ("ms_per_step", NUM), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
@@ -67,6 +88,8 @@ def test_committed_bench_lines_follow_the_contract(pattern, n1):
         lines = [ln for ln in open(f).read().splitlines() if ln.startswith("{")]
         assert len(lines) == 1, f
         check_line(json.loads(lines[0]), n1)
+        if os.path.basename(f) >= "r04":
+            check_sequence_blocks(json.loads(lines[0]), n1)
 
 
 def test_native_group_child_leaves_the_launcher_environment_behind(monkeypatch):
