@@ -476,18 +476,19 @@ def sharded_config(ca, torch, dist, wl, rank, world, local_rank, steps, warmup):
 
 def sharded_sequence(ca, torch, dist, wl, d_frames, rank, world, local_rank, K=16):
     """A tracked sequence with the sector grid split over the ranks in contiguous blocks (BASELINE config 4's
-    shape): every rank keeps the undeformed pyramid (built ONCE) and its block's guess history; per window of K pairs ONE
-    broadcast of the K new frames from rank 0 - issued before the window it overlaps is launched, into the other half of a
-    double buffer - every rank solves the window for its block (frame-pipelined instances), ONE all-gather of K x block
-    records.  Beside it the whole grid on one GPU (every rank on its own device, no collectives).  Every rank must call this;
-    failures are agreed on before and after the timed regions."""
-    from correlation_amd.workload import shard_range
+    shape) - correlation_amd/distributed.py: ShardedWindowSequence (covered by a 2-rank gloo test on the CPU): every rank keeps
+    the undeformed pyramid (built ONCE) and its block's guess history; per window of K pairs ONE broadcast of the K new frames
+    from rank 0 - issued before the window it overlaps is launched, into the other half of a double buffer - every rank solves
+    the window for its block (frame-pipelined instances), ONE all-gather of K x block records (behind the next window).
+    Beside it the whole grid on one GPU (every rank on its own device, no collectives).  Every rank must call this; failures
+    are agreed on before and after the timed regions."""
+    from correlation_amd.distributed import ShardedWindowSequence
     use_dist = dist is not None
     dev = torch.device("cuda", local_rank)
     n = int(d_frames.shape[0]) - 1
     size = int(d_frames.shape[1])
     K = min(K, n)
-    c, zero = (size / 2 - 0.5, size / 2 - 0.5), np.zeros(6, np.float32)
+    c = (size / 2 - 0.5, size / 2 - 0.5)
     info = {"workload": wl.name, "n_ranks": dist.get_world_size() if use_dist else 1, "sectors_total": wl.hs * wl.vs, "pairs": n,
             "window_pairs": K, "scaling": "strong"}
 
@@ -498,74 +499,31 @@ def sharded_sequence(ca, torch, dist, wl, d_frames, rank, world, local_rank, K=1
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return bool(flag.item())
 
-    full = shard = None
-    err = None
+    engines, shard, full, err = [], None, None, None
     try:
-        def engine(first, count):
+        def sequence(d):
             e = ca.HipCorrelationEngine(interpolation=ca.IM_BICUBIC, fitting_model=wl.model, py_stop=wl.py_stop, device=local_rank)
-            e.set_rect_grid(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, wl.hs, wl.vs, first, count)
-            e.commit_sectors()
-            e.sequence_reserve(2 * K)
-            return e
-        first, count = shard_range(wl.hs * wl.vs, rank, world)
-        shard = engine(first, count)
-        full = engine(0, wl.hs * wl.vs) if world > 1 else shard
-        cap = (wl.hs * wl.vs + world - 1) // world
-        stage = [torch.empty((K, size, size), dtype=torch.uint8, device=dev) for _ in range(2)]     # frames of a window, as they arrive
-        d_block = torch.zeros((K, cap, 48), dtype=torch.uint8, device=dev)
-        d_all = torch.empty((world, K, cap, 48), dtype=torch.uint8, device=dev) if use_dist else None
-        comm = torch.cuda.Stream(dev)
+            engines.append(e)
+            sq = ShardedWindowSequence(e, d, dev, window=K)
+            sq.set_rect_grid(wl.x_begin, wl.x_begin, wl.x_end, wl.x_end, wl.hs, wl.vs)
+            return sq
+        shard = sequence(dist if use_dist else None)
+        full = sequence(None) if world > 1 else shard
     except Exception as ex:   # noqa: BLE001
         err = repr(ex)
     if not agree(err is None):
-        for e in {id(x): x for x in (full, shard) if x is not None}.values():
+        for e in engines:
             e.close()
         info["error"] = err or "set-up failed on another rank"
         return info
 
-    def fetch_window(w, buf, sharded):
-        """frames of window w -> stage[buf]: rank 0's, broadcast (sharded run), or the rank's own copy of the sequence"""
-        lo = 1 + w * K
-        k = min(K, n - w * K)
-        with torch.cuda.stream(comm):
-            if rank == 0 or not sharded:
-                stage[buf][:k].copy_(d_frames[lo:lo + k], non_blocking=True)
-            return dist.broadcast(stage[buf], src=0, async_op=True) if (use_dist and sharded) else None
-
-    def run(e, sharded):
-        """the whole sequence once; returns wall ms"""
-        n_win = (n + K - 1) // K
+    def run(sq, barrier):
         torch.cuda.synchronize(dev)
-        if use_dist and sharded:
+        if use_dist and barrier:
             dist.barrier()
         t0 = time.perf_counter()
-        e.set_image_device(ca.IMG_UND, d_frames[0].data_ptr(), size, size)      # the undeformed pyramid: once per sequence
-        h = fetch_window(0, 0, sharded)
-        gather = None
-        for w in range(n_win):
-            k = min(K, n - w * K)
-            if h is not None:
-                h.wait()
-            comm.synchronize()                                                   # the frames of window w have arrived
-            for i in range(k):
-                e.sequence_set_frame_device((w % 2) * K + i, stage[w % 2][i].data_ptr(), size, size)
-            if w + 1 < n_win:
-                h = fetch_window(w + 1, (w + 1) % 2, sharded)                    # travels while window w is solved
-            e.adjust_initial_guess(w * K, True, zero, c)
-            e.correlate_sequence_async(k, first_slot=(w % 2) * K, constant_velocity=True, host_records=False)
-            e.wait_sequence(False)
-            if use_dist and sharded:
-                if gather is not None:
-                    gather.wait()                                                # (the previous all-gather has read d_block)
-                e.copy_sequence_records_device(d_block.data_ptr(), cap)          # [k][S_me] -> the padded block [K][cap], engine's stream
-                e.synchronize()
-                with torch.cuda.stream(comm):
-                    gather = dist.all_gather_into_tensor(d_all.view(-1, 48), d_block.view(-1, 48), async_op=True)
-        if gather is not None:
-            gather.wait()
-        comm.synchronize()
-        e.synchronize()
-        if use_dist and sharded:
+        sq.run(d_frames, constant_velocity=True, center=c, fetch=False)
+        if use_dist and barrier:
             dist.barrier()
         torch.cuda.synchronize(dev)
         return (time.perf_counter() - t0) * 1e3
@@ -590,10 +548,11 @@ def sharded_sequence(ca, torch, dist, wl, d_frames, rank, world, local_rank, K=1
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms_sharded, ms_one = float(t[0].item()), float(t[1].item())
         info.update({"ms_per_pair": ms_sharded / n, "ms_per_pair_1gpu": ms_one / n, "speedup_vs_1gpu": ms_one / ms_sharded,
-                     "sectors_per_rank": int(shard.n_sectors),
+                     "sectors_per_rank": int(shard.count),
                      "step": "per window: one broadcast of its frames (behind the window before), pyramids, the frame-pipelined solve of "
-                             "the rank's block, one all-gather of its records; the undeformed pyramid once per sequence"})
-    for e in {id(x): x for x in (full, shard) if x is not None}.values():
+                             "the rank's block, one all-gather of its records (behind the next window); the undeformed pyramid once per "
+                             "sequence"})
+    for e in engines:
         e.close()
     return info
 

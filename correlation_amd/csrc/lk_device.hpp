@@ -92,6 +92,8 @@ struct LkSolveArgs {
   int mark_stale;        // reference-order mode (any instance of its launch chain): a sector whose very first evaluation fails
                          //   reports the stale-iteration marker instead of 0 (lk_stale_iterations_kernel resolves it)
   int persistent;        // 1: groups pull sectors from `queue`; 0: one sector per group by position
+  int rows_used;         // positional launches of 16-lane rows: rows of a wavefront that get a sector (0 / 4: all; 3, 2: the
+                         //   reference-order rows deal the idle rows' lanes to the wavefront's sectors)
   int starved_max;       // a level with at most this many samples is "starved" (default 2 P)
   int keep_sums;         // 1 (default): a rejected trip continues from the kept sums of the last good parameters;
                          //   0 (LK_KEEP_SUMS=0, tests): it evaluates there again, as the reference does - same records

@@ -2243,6 +2243,10 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
         // of sectors (neighbouring sectors share image rows in its L2)
         const int wg_slot = ((int)blockIdx.x & 7) * a.chunk + ((int)blockIdx.x >> 3);
         slot = first_fetch ? wg_slot * (THREADS / GROUP) + (int)threadIdx.x / GROUP : a.n_sectors;
+        if constexpr (FLAT) { // (fewer sectors per wavefront: the rows without one lend their lanes from the start)
+          if (a.rows_used > 0 && a.rows_used < 4)
+            slot = (first_fetch && (int)threadIdx.x / GROUP < a.rows_used) ? wg_slot * a.rows_used + (int)threadIdx.x / GROUP : a.n_sectors;
+        }
         if (GROUP == 512 && a.team_w > 1) // a team's workgroups all take the team's sector
           slot = first_fetch ? team.slot : a.n_sectors;
         first_fetch = false;
@@ -4049,9 +4053,13 @@ static hipError_t launch_solve_gs(const LkSolveArgs &a, hipStream_t st) {
     resident = resident_workgroups(lk_solve_kernel<MODEL, INTERP, GROUP, THREADS, SAFE, REF>, THREADS);
     resident_cache.store(resident, std::memory_order_relaxed);
   }
-  const int per_wg = THREADS / GROUP;
-  const int want = (a.n_sectors + per_wg - 1) / per_wg;
   LkSolveArgs b = a;
+  if (REF && GROUP == 16) {
+    static const int rows_env = [] { const char *f = getenv("LK_FLAT_ROWS"); return f ? atoi(f) : 0; }(); // tuning hook
+    b.rows_used = rows_env >= 1 && rows_env <= 4 ? rows_env : 0;
+  }
+  const int per_wg = (REF && GROUP == 16 && b.rows_used > 0) ? b.rows_used : THREADS / GROUP;
+  const int want = (a.n_sectors + per_wg - 1) / per_wg;
   static const int force_persistent = [] { // tuning / test hook
     const char *f = getenv("LK_FORCE_PERSISTENT");
     return f ? atoi(f) : -1;

@@ -179,3 +179,130 @@ class ShardedSequence:
             if stop:
                 break
         return done
+
+
+class ShardedWindowSequence:
+    """An Eulerian sequence in frame-pipelined WINDOWS over several GPUs (DESIGN.md sections 3.5, 7): every rank keeps the
+    undeformed pyramid (built once) and its block of sectors with their guess history; per window of K pairs ONE
+    broadcast of the K new frames from rank 0 - issued before the window it overlaps is launched, into the other half of
+    a double buffer - every rank solves the window for its block (lk_correlate_sequence_async), ONE all-gather of
+    K x block records.  `engine` needs sequence_reserve / sequence_set_frame[_device] / adjust_initial_guess /
+    correlate_sequence_async / wait_sequence (+ copy_sequence_records_device on the device path); the CPU tests drive
+    it with a stand-in under gloo."""
+
+    def __init__(self, engine, dist=None, device=None, window=16):
+        self.e, self.dist, self.device = engine, dist, device
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.K = int(window)
+        self.total = self.first = self.count = 0
+        self.comm = None
+        if device is not None:
+            import torch
+            self.comm = torch.cuda.Stream(device)
+
+    def set_rect_grid(self, x_begin, y_begin, x_end, y_end, hs, vs):
+        self.total = hs * vs
+        self.first, self.count = shard_range(self.total, self.rank, self.world)
+        self.e.set_rect_grid(x_begin, y_begin, x_end, y_end, hs, vs, self.first, self.count)
+        self.e.commit_sectors()
+
+    def run(self, frames, constant_velocity=True, global_guess=None, center=(0.0, 0.0), fetch=True, sharded=True):
+        """frames: [n + 1, H, W] uint8 - a numpy array / list (host path) or a torch tensor on `device`; their content matters
+        on rank 0 only (sharded) - frame 0 is the undeformed image.  Returns the records [n][S] of ALL sectors in sector
+        order (fetch; same on every rank), or None (the last window's gathered records stay on the device)."""
+        import torch
+        from ._ffi import IMG_UND, RESULT_DTYPE
+        n = len(frames) - 1
+        K = min(self.K, n)
+        n_win = (n + K - 1) // K
+        rec_bytes = RESULT_DTYPE.itemsize
+        cap = (self.total + self.world - 1) // self.world
+        use_dist = self.dist is not None and self.world > 1 and sharded
+        gg = np.zeros(6, np.float32) if global_guess is None else np.asarray(global_guess, np.float32)
+        dev = self.device
+        H, W = int(frames[0].shape[0]), int(frames[0].shape[1])
+        self.e.sequence_reserve(2 * K)
+        out = np.zeros((n, self.total), RESULT_DTYPE) if fetch else None
+        if dev is None:   # ---- host path (numpy frames, CPU collectives: the gloo tests)
+            und = torch.from_numpy(np.ascontiguousarray(frames[0], np.uint8).copy())
+            if use_dist:
+                self.dist.broadcast(und, src=0)
+            self.e.set_image(IMG_UND, und.numpy())
+            for w in range(n_win):
+                k = min(K, n - w * K)
+                stage = torch.from_numpy(np.ascontiguousarray(np.stack([frames[1 + w * K + i] for i in range(k)]), np.uint8).copy())
+                if use_dist:
+                    self.dist.broadcast(stage, src=0)
+                for i in range(k):
+                    self.e.sequence_set_frame((w % 2) * K + i, stage[i].numpy())
+                self.e.adjust_initial_guess(w * K, constant_velocity, gg, center)
+                self.e.correlate_sequence_async(k, first_slot=(w % 2) * K, constant_velocity=constant_velocity, host_records=True)
+                local = self.e.wait_sequence(True)                                   # [k][count]
+                block = np.zeros((K, cap, rec_bytes), np.uint8)
+                block[:k, :self.count] = local.view(np.uint8).reshape(k, self.count, rec_bytes)
+                if use_dist:
+                    gathered = torch.empty((self.world, K, cap, rec_bytes), dtype=torch.uint8)
+                    self.dist.all_gather_into_tensor(gathered.view(-1, rec_bytes), torch.from_numpy(block).view(-1, rec_bytes))
+                    allb = gathered.numpy()
+                else:
+                    allb = block[None]
+                if fetch:
+                    self._scatter(out, allb, w * K, k, use_dist)
+            return out
+        # ---- device path: frames and records stay in HBM; collectives on a communication stream of their own
+        stage = [torch.empty((K, H, W), dtype=torch.uint8, device=dev) for _ in range(2)]
+        d_block = torch.zeros((K, cap, rec_bytes), dtype=torch.uint8, device=dev)
+        d_all = [torch.empty((self.world, K, cap, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(2)] if use_dist else None
+
+        def fetch_window(w, buf):
+            lo, k = 1 + w * K, min(K, n - w * K)
+            with torch.cuda.stream(self.comm):
+                if self.rank == 0 or not use_dist:
+                    stage[buf][:k].copy_(frames[lo:lo + k], non_blocking=True)
+                return self.dist.broadcast(stage[buf], src=0, async_op=True) if use_dist else None
+
+        self.e.set_image_device(IMG_UND, frames[0].data_ptr(), H, W)               # the undeformed pyramid: once per sequence
+        h = fetch_window(0, 0)
+        gather = None
+        pending = None                                                              # (window, frames) whose gathered records are to be copied out
+        for w in range(n_win):
+            k = min(K, n - w * K)
+            if h is not None:
+                h.wait()
+            self.comm.synchronize()                                                  # the frames of window w have arrived
+            for i in range(k):
+                self.e.sequence_set_frame_device((w % 2) * K + i, stage[w % 2][i].data_ptr(), H, W)
+            if w + 1 < n_win:
+                h = fetch_window(w + 1, (w + 1) % 2)                                 # travels while window w is solved
+            self.e.adjust_initial_guess(w * K, constant_velocity, gg, center)
+            self.e.correlate_sequence_async(k, first_slot=(w % 2) * K, constant_velocity=constant_velocity, host_records=False)
+            self.e.wait_sequence(False)
+            if gather is not None:
+                gather.wait()                                                        # (the previous all-gather has read d_block)
+            if fetch and pending is not None:
+                self._scatter(out, d_all[pending[0] % 2].cpu().numpy(), pending[0] * K, pending[1], True)
+                pending = None
+            self.e.copy_sequence_records_device(d_block.data_ptr(), cap)             # [k][count] -> the padded block [K][cap]
+            self.e.synchronize()
+            if use_dist:
+                with torch.cuda.stream(self.comm):
+                    gather = self.dist.all_gather_into_tensor(d_all[w % 2].view(-1, rec_bytes), d_block.view(-1, rec_bytes), async_op=True)
+                pending = (w, k)
+            elif fetch:
+                self._scatter(out, d_block.cpu().numpy()[None], w * K, k, False)
+        if gather is not None:
+            gather.wait()
+        self.comm.synchronize()
+        if fetch and pending is not None:
+            self._scatter(out, d_all[pending[0] % 2].cpu().numpy(), pending[0] * K, pending[1], True)
+        self.e.synchronize()
+        return out
+
+    def _scatter(self, out, blocks, first_pair, k, gathered):
+        """blocks [ranks][K][cap][48] -> out[first_pair : first_pair + k] in global sector order"""
+        from ._ffi import RESULT_DTYPE
+        for r in range(blocks.shape[0]):
+            f, c = shard_range(self.total, r, self.world) if gathered else (0, self.count)
+            rec = np.ascontiguousarray(blocks[r, :k, :c]).reshape(-1).view(RESULT_DTYPE).reshape(k, c)
+            out[first_pair:first_pair + k, f:f + c] = rec
