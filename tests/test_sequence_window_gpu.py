@@ -259,3 +259,25 @@ def test_frames_from_pinned_host_memory_upload_without_waiting(frames448):
         assert b.lib.lk_unpin_host_memory(C.c_void_p(f.ctypes.data)) == 0
     a.close()
     b.close()
+
+
+def test_sharded_window_sequence_device_path_on_one_rank(frames448):
+    """correlation_amd/distributed.py: ShardedWindowSequence with frames and records in HBM (the bench's sharded sequences;
+    its collectives are covered by the 2-rank gloo test on the CPU): windows of 3 through the class = one window of 7"""
+    import torch
+    from correlation_amd.distributed import ShardedWindowSequence
+    frames = np.stack(frames448)
+    d = torch.from_numpy(frames).to("cuda")
+    e = make_engine("batch_invariant")
+    sq = ShardedWindowSequence(e, None, torch.device("cuda", 0), window=3)
+    n = int((448 - 49) // 8.95)
+    sq.set_rect_grid(24.0, 24.0, 448.0 - 25.0, 448.0 - 25.0, n, n)
+    got = sq.run(d, center=(223.5, 223.5))
+    a = make_engine("batch_invariant")
+    a.set_undeformed_image(frames[0])
+    domain(a, "c4like", 448)
+    a.sequence_reserve(7)
+    _, want = window(a, frames, 0, 7, center=(223.5, 223.5))
+    assert got.shape == want.shape and got.tobytes() == want.tobytes()
+    e.close()
+    a.close()
