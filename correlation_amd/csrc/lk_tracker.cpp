@@ -842,9 +842,11 @@ int lk_sequence_frame(lk_engine *e, lk_tracker *t, int frame, const char *und_na
   int rc = lk_tracker_begin_frame(t, frame, cmds.data(), guesses.data());
   if (rc)
     return rc;
+  bool moved = false;
   if (frame == 0) {
     rc = register_sectors(e, t, cmds);
   } else if (S > 0 && cmds[0].kind != LK_SECTOR_KEEP) {
+    moved = true;
     std::vector<float> off(2 * (size_t)S), cen(2 * (size_t)S);
     for (int s = 0; s < S; ++s) {
       off[2 * (size_t)s] = cmds[(size_t)s].offset_x;
@@ -865,8 +867,8 @@ int lk_sequence_frame(lk_engine *e, lk_tracker *t, int frame, const char *und_na
     return rc;
   int first_unsolved = S;
   rc = lk_tracker_end_frame(t, frame, und_name, def_name, results.data(), &first_unsolved, stop_sequence);
-  if (!rc && first_unsolved < S && frame > 0)
-    rc = lk_restore_sectors(e, first_unsolved); // their samples stay where the previous frame left them
+  if (!rc && first_unsolved < S && moved)
+    rc = lk_restore_sectors(e, first_unsolved); // their samples stay where the previous frame left them (Eulerian: nothing moved)
   return rc;
 }
 
@@ -902,7 +904,14 @@ int lk_sequence_run(lk_engine *e, lk_tracker *t, int n_frames, lk_frame_provider
   // the tracker's bookkeeping of pair k (update_results, global results, report) runs BEHIND that
   // solve instead of between two solves.
   const char *sync_env = std::getenv("LK_SEQ_SYNC"); // test / comparison hook
-  const bool overlapped = !rc && t->cfg.deformation == LK_DEF_EULERIAN && t->cfg.error_mode == LK_ERRMODE_CONTINUE &&
+  // (stopAll - the sequence ends with the first frame that has an error, manager_class.cpp:1485-1486 - only in windows: they
+  // compute ahead and the frames behind the stopping one are discarded; no frame before it had an error, so nothing a later
+  // frame was started from changes.  stopFrame skips the rest of a frame and goes on: the frames computed ahead would have
+  // started from results the reference never had - it keeps the synchronous loop)
+  const char *win_env0 = std::getenv("LK_SEQ_WINDOW");
+  const bool windows_wanted = !(win_env0 && std::atoi(win_env0) <= 1) && n_frames > 2;
+  const bool overlapped = !rc && t->cfg.deformation == LK_DEF_EULERIAN &&
+                          (t->cfg.error_mode == LK_ERRMODE_CONTINUE || (t->cfg.error_mode == LK_ERRMODE_STOP_ALL && windows_wanted)) &&
                           t->cfg.domain_type == LK_DOMAIN_RECT && !(sync_env && std::atoi(sync_env) != 0);
   if (overlapped) {
     const char *check_env = std::getenv("LK_SEQ_CHECK"); // tests: device guesses == the tracker's, bit for bit
@@ -941,7 +950,7 @@ int lk_sequence_run(lk_engine *e, lk_tracker *t, int n_frames, lk_frame_provider
     // mode (tests/test_sequence_window_gpu.py).
     const char *win_env = std::getenv("LK_SEQ_WINDOW");
     const int K = std::min(pairs, win_env ? std::max(1, std::atoi(win_env)) : 16);
-    if (!rc && K >= 2) {
+    if (!rc && (K >= 2 || t->cfg.error_mode == LK_ERRMODE_STOP_ALL)) {
       const int R = 2 * K;
       rc = lk_sequence_reserve(e, R);
       std::vector<std::string> frame_name((size_t)n_frames);
@@ -969,9 +978,10 @@ int lk_sequence_run(lk_engine *e, lk_tracker *t, int n_frames, lk_frame_provider
         }
       std::future<int> next;
       int have_first = -1, have_n = 0, have_buf = 0; // a solved window whose bookkeeping is still to be done
+      bool stopped = false;                          // stopAll: a frame had an error - the frames behind it are discarded
       auto bookkeeping = [&]() -> int {
         int r = LK_ERROR_NONE;
-        for (int i = 0; i < have_n && !r; ++i) {
+        for (int i = 0; i < have_n && !r && !stopped; ++i) {
           const int k = have_first + i;
           const std::string &und_k = t->cfg.reference_image == LK_REF_PREVIOUS ? frame_name[(size_t)k] : frame_name[0];
           if (k > 0) // (frame 0's begin_frame ran before the sectors were registered; its guesses are still in `guesses`)
@@ -981,12 +991,13 @@ int lk_sequence_run(lk_engine *e, lk_tracker *t, int n_frames, lk_frame_provider
             if (std::memcmp(dev, guesses.data(), 6 * (size_t)S * sizeof(float)) != 0)
               r = t->fail(LK_ERROR_BAD_DOMAIN, "lk_sequence_run: device guesses differ from the tracker's");
           }
-          int first_unsolved = S, stop = 0; // (never a stop: the continue policy is a condition of this path)
+          int first_unsolved = S, stop = 0; // (stopAll: the frame with the first error ends the sequence)
           if (!r)
             r = lk_tracker_end_frame(t, k, und_k.c_str(), frame_name[(size_t)k + 1].c_str(), win[have_buf] + (size_t)i * (size_t)S,
                                      &first_unsolved, &stop);
           if (!r && pairs_done)
             *pairs_done = k + 1;
+          stopped = !r && stop != 0;
         }
         have_n = 0;
         return r;
@@ -1028,11 +1039,13 @@ int lk_sequence_run(lk_engine *e, lk_tracker *t, int n_frames, lk_frame_provider
         }
         if (!rc && check)
           rc = lk_get_sequence_guesses(e, win_guess[buf].data());
-        if (!rc) {
+        if (!rc && !stopped) {
           have_first = first;
           have_n = n;
           have_buf = buf;
         }
+        if (stopped)
+          break;
       }
       if (next.valid())
         (void)next.get();

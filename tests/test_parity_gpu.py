@@ -1160,6 +1160,36 @@ def test_overlapped_frame_loop_equals_the_synchronous_one(monkeypatch, model, re
 
 
 @pytest.mark.gpu
+def test_windows_under_the_stop_all_policy_end_where_the_synchronous_loop_ends(monkeypatch):
+    """stopAll (manager_class.cpp:1485-1486): the sequence ends with the first frame in which a sector fails.  The frame
+    loop computes its windows ahead and discards what lies behind that frame; no frame before it had an error, so the
+    report must be the synchronous loop's text, and the same number of pairs must have been correlated.  Frame 6 of ten is
+    blank: no gradient, every sector of pair 5 fails."""
+    from correlation_amd import tracker as tk
+    frames = ca.speckle.speckle_sequence(320, 288, 10, velocity=(0.8, -0.45), dilation=5e-4, seed=21)
+    frames[6] = np.full_like(frames[6], 90)
+    names = [f"f{i}" for i in range(len(frames))]
+
+    def run(sync, window):
+        monkeypatch.setenv("LK_SEQ_SYNC", "1" if sync else "0")
+        monkeypatch.setenv("LK_SEQ_WINDOW", str(window))
+        e = ca.HipCorrelationEngine(fitting_model=ca.FM_UVUXUYVXVY)
+        e.set_batch_invariant(True)
+        t = tk.SequenceTracker(ca.FM_UVUXUYVXVY, tk.DOMAIN_RECT, tk.DEF_EULERIAN, tk.REF_FIRST, tk.ERRMODE_STOP_ALL,
+                               [0.4, -0.2, 1e-3, 5e-4, -5e-4, 2e-3], lib=e.lib)
+        t.set_rect_domain(60.0, 60.0, 259.0, 227.0, 160.0, 144.0, 6, 5)    # (well inside the image: no sector leaves it)
+        done = tk.run_sequence(e, t, frames, names)
+        text, res = t.report(), t.results().tobytes()
+        e.close(), t.close()
+        return done, text, res
+
+    want = run(True, 1)
+    assert 2 <= want[0] < len(frames) - 1, "the sequence is meant to stop in the middle"
+    for window in (3, 16):
+        assert run(False, window) == want, window
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", [0, 1])
 def test_update_sector_equals_the_frame_loop(mode):
     """CudaClass::updatePolygon's call shape (one sector, the engine's own last record) must move
