@@ -9,6 +9,8 @@
 //   sector state center[S] (float2), guess[S][6], last_p[S][6], prev_p[S][6],
 //               result[S] (48 B, layout of CorrelationResult), stats[S][4].
 //   rectangular sectors have no list at all: int4 {x_first, y_first, width, n} per level.
+//   sequences   a ring of K deformed-frame pyramids + per-window records / counters / granule chain (frame-pipelined
+//               windows: lk_correlate_sequence_async - every sector advances through the frames of a window on its own).
 // Everything for an image pair is resident; lk_correlate_all* is one launch per size class
 // (16 / 32 / 64 lanes, 4 / 8 wavefronts, teams) on one stream, preceded by the one-lane kernel
 // and its finisher when the class has a starved pyramid level.

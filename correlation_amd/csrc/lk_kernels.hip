@@ -12,6 +12,11 @@
 //                      Reference-order mode (lk_set_reference_order): the SAFE 16- / 64-lane instances
 //                      solve every level with evaluate_ordered (the CPU engine's summation order for any
 //                      number_of_threads) + that QR - records byte-identical to the CPU class.
+//                      Frame-pipelined instances (template parameter SEQ, lk_correlate_sequence_async): the same state
+//                      machine over (frame, sector) tickets of a window of resident frames, drawn frame-major; a sector's
+//                      parameters travel from frame to frame through a chain of 8-byte granules, its guess
+//                      (manager_class.cpp:2677-2699) is formed in the kernel, a group whose sector's previous frame is
+//                      not in yet waits without holding up the other sectors of its wavefront (PH_WAIT).
 //                      Scheduling inside a wavefront: level alignment, solo (32 lanes) and adaptive
 //                      width (16 lanes) - idle lanes join the sectors still being solved.  Kept sums:
 //                      a rejected LM trip continues from the sums of the last accepted evaluation.
