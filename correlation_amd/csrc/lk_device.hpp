@@ -119,6 +119,7 @@ struct LkSolveArgs {
   float *seq_prev_p_out;        // [S][6] ... and after it (written by the window's last frame; a buffer of its own)
   float *seq_guess_out;         // optional [seq_frames][seq_stride][6]: the guesses the frames were solved from
   uint32_t *seq_flags;          // [0]: a wait ran into its bound (the launch is void); [1]: a fast-flavour solve met a bad pivot
+  int seq_fault;                // test hook (LK_SEQ_FAULT = f + 1): frame f of the launch's first sector never publishes - the bounded wait's exit
 };
 
 // ROI -> level-0 sample lists on the device (cudaPolygon's mask + compaction, cuda_polygon.cuh:180-292,

@@ -3008,6 +3008,8 @@ static int launch_window(lk_engine *e, bool force_safe_flavour) {
       a.seq_prev_p_out = e->d_prev_p_alt.p;
       a.seq_guess_out = w.want_guesses ? e->d_seq_guess.p : nullptr;
       a.seq_flags = e->d_seq_flags.p;
+      if (const char *f = std::getenv("LK_SEQ_FAULT")) // test hook, read per launch: a frame that never publishes
+        a.seq_fault = std::atoi(f);
       int flavour = (force_safe_flavour || safe_flavour(e) || e->class_starved[c]) ? 1 : 0;
       if (e->reference_order > 0) {
         flavour = 2;

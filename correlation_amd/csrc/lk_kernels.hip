@@ -2194,6 +2194,8 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 64 ? (GROUP == 16 && !SAF
         // IS the flag (lk_device.hpp: kLkSeqChainWords)
         unsigned long long *ch = a.seq_chain + (size_t)k.s * kLkSeqChainWords + (size_t)(cur_frame & 1) * 8;
         const unsigned long long tag = (unsigned long long)(uint32_t)(cur_frame + 1) << 32;
+        const bool lost = a.seq_fault != 0 && cur_frame == a.seq_fault - 1 && k.s == (a.order ? (int)a.order[0] : 0); // (test hook)
+        if (!lost)
 #pragma unroll
         for (int i = 0; i < P; ++i)
           __hip_atomic_store(ch + i, tag | (unsigned long long)__float_as_uint(r.resultingParameters[i]), __ATOMIC_RELAXED,

@@ -281,3 +281,69 @@ def test_sharded_window_sequence_device_path_on_one_rank(frames448):
     assert got.shape == want.shape and got.tobytes() == want.tobytes()
     e.close()
     a.close()
+
+
+def test_two_windows_at_once_need_no_co_residency():
+    """Two engines launch a window each, at the same time, each grid sized for an empty GPU (config 2's 10 000 sectors: 3200
+    wavefronts per window for 4096 slots): the second kernel is only partly resident while the first one runs.  A group waits
+    only for tickets that were drawn earlier - by wavefronts that are running - so both windows finish, with the bytes of their
+    solo runs."""
+    n = 6
+    frames = full_size_frames(2 * n + 1)
+    c = (1023.5, 1023.5)
+
+    def engine(first_frame):
+        e = make_engine("batch_invariant")
+        e.set_undeformed_image(frames[0])
+        e.set_rect_grid(C2.x_begin, C2.x_begin, C2.x_end, C2.x_end, C2.hs, C2.vs)
+        e.commit_sectors()
+        e.sequence_reserve(n)
+        for i in range(n):
+            e.sequence_set_frame(i, frames[first_frame + i + 1])
+        e.adjust_initial_guess(0, False, ZERO, c)
+        return e
+
+    a, b = engine(0), engine(n)
+    solo_a = a.correlate_sequence(n, constant_velocity=False)
+    solo_b = b.correlate_sequence(n, constant_velocity=False)
+    a.adjust_initial_guess(0, False, ZERO, c)
+    b.adjust_initial_guess(0, False, ZERO, c)
+    a.correlate_sequence_async(n, constant_velocity=False)
+    b.correlate_sequence_async(n, constant_velocity=False)
+    both_b = b.wait_sequence()
+    both_a = a.wait_sequence()
+    assert both_a.tobytes() == solo_a.tobytes() and both_b.tobytes() == solo_b.tobytes()
+    assert (solo_b["error_code"][0] == 0).mean() > 0.9
+    a.close()
+    b.close()
+
+
+def test_a_frame_that_never_publishes_voids_the_window_instead_of_hanging_it(frames448, monkeypatch):
+    """The wait of a (frame, sector) for its sector's previous frame is bounded.  Test hook LK_SEQ_FAULT = f + 1: frame f of the
+    first sector never publishes its parameters (what a lost wavefront would look like); the group that holds that sector's next
+    frame gives up after ~1 s and raises the window's flag, every other waiter sees it and leaves, the grid drains, and
+    lk_wait_sequence reports LK_ERROR_DEVICE.  The engine stays usable: the same window solved again (a sequence restarts from its
+    first frame after a void window) gives the loop's records."""
+    frames, n, c = frames448, 5, (223.5, 223.5)
+    e = make_engine("batch_invariant")
+    e.set_undeformed_image(frames[0])
+    domain(e, "c2like", 448)
+    e.sequence_reserve(n)
+    for i in range(n):
+        e.sequence_set_frame(i, frames[i + 1])
+    e.adjust_initial_guess(0, True, ZERO, c)
+    monkeypatch.setenv("LK_SEQ_FAULT", "2")          # frame 1 of sector 0 is lost
+    e.correlate_sequence_async(n)
+    with pytest.raises(ca.LkError) as err:
+        e.wait_sequence()
+    assert err.value.code == ca.ERROR_DEVICE and "bound" in str(err.value)
+    monkeypatch.delenv("LK_SEQ_FAULT")
+    e.adjust_initial_guess(0, True, ZERO, c)
+    got = e.correlate_sequence(n)
+    a = make_engine("batch_invariant")
+    a.set_undeformed_image(frames[0])
+    domain(a, "c2like", 448)
+    _, want = loop(a, frames, 0, n, center=c)
+    assert got.tobytes() == want.tobytes()
+    a.close()
+    e.close()
