@@ -170,6 +170,8 @@ SYMBOLS = {
     "lk_group_synchronize": (C.c_int, [_P]),
     "lk_group_get_stats": (C.c_int, [_P, C.POINTER(LkStats)]),
     "lk_load_pgm": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), _I, _I]),
+    "lk_load_image": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), _I, _I]),
+    "lk_decode_image": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), _I, _I]),
     "lk_free_image": (None, [C.POINTER(C.c_uint8)]),
 }
 

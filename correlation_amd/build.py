@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblk_engine.so")
-SOURCES = ["lk_engine.cpp", "lk_tracker.cpp", "lk_group.cpp", "lk_kernels.hip"]
+SOURCES = ["lk_engine.cpp", "lk_tracker.cpp", "lk_group.cpp", "lk_image_io.cpp", "lk_kernels.hip"]
 HEADERS = ["lk_device.hpp", "lk_roi.hpp", os.path.join("..", "..", "include", "lk_engine.h"),
            os.path.join("..", "..", "include", "lk_tracker.h"), os.path.join("..", "..", "include", "lk_group.h")]
 
@@ -75,6 +75,7 @@ def build(force=False, verbose=False):
     link = [hipcc_path(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + [o for o, _ in results] + [
         "-lrocprofiler-sdk-roctx",   # roctx ranges (lk_engine.cpp: struct Range)
         "-lrccl",                    # lk_group.cpp: ncclBroadcast / ncclAllGather over xGMI
+        "-lz",                       # lk_image_io.cpp: inflate + crc32 for PNG
     ]
     r = subprocess.run(link, cwd=CSRC, capture_output=True, text=True)
     if r.returncode != 0:

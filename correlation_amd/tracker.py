@@ -163,3 +163,28 @@ def load_pgm(path, lib=None):
     out = np.ctypeslib.as_array(px, (r.value, c.value)).copy()
     lib.lk_free_image(px)
     return out
+
+
+def load_image(path, lib=None):
+    """lk_load_image: the file as 8-bit grey, what cv::imread(path, IMREAD_GRAYSCALE) hands the reference
+    (PNG, uncompressed BMP, PNM)"""
+    lib = lib or _ffi.load_library()
+    px, r, c = C.POINTER(C.c_uint8)(), C.c_int(), C.c_int()
+    rc = lib.lk_load_image(str(path).encode(), C.byref(px), C.byref(r), C.byref(c))
+    if rc != 0:
+        raise IOError(f"lk_load_image({path}) failed ({rc})")
+    out = np.ctypeslib.as_array(px, (r.value, c.value)).copy()
+    lib.lk_free_image(px)
+    return out
+
+
+def decode_image(data, lib=None):
+    """lk_decode_image: load_image for a file already in memory (bytes)"""
+    lib = lib or _ffi.load_library()
+    px, r, c = C.POINTER(C.c_uint8)(), C.c_int(), C.c_int()
+    rc = lib.lk_decode_image(bytes(data), len(data), C.byref(px), C.byref(r), C.byref(c))
+    if rc != 0:
+        raise IOError(f"lk_decode_image failed ({rc})")
+    out = np.ctypeslib.as_array(px, (r.value, c.value)).copy()
+    lib.lk_free_image(px)
+    return out

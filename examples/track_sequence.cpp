@@ -6,7 +6,7 @@
 //       -Wl,-rpath,$PWD/correlation_amd -o track_sequence          (one command line)
 //   ./track_sequence report.csv eulerian|lagrangian|strict  hs vs  frame0.pgm frame1.pgm [frame2.pgm ...]
 //
-// Frames are binary PGM (P5).  The rectangular domain is the image minus a 24-pixel margin, split
+// Frames are whatever lk_load_image decodes (PNG, BMP, PNM) - the 8-bit grey cv::imread(path, IMREAD_GRAYSCALE) would give.  The rectangular domain is the image minus a 24-pixel margin, split
 // into hs x vs sectors; affine model, bicubic interpolation, pyramid levels 0/1/2, zero global guess.
 #include <cstdio>
 #include <cstdlib>
@@ -28,7 +28,7 @@ const uint8_t *provide(void *user, int index, int *rows, int *cols, int *step, c
   Frames *f = static_cast<Frames *>(user);
   uint8_t *px = nullptr;
   int r = 0, c = 0;
-  if (lk_load_pgm(f->paths[(size_t)index].c_str(), &px, &r, &c) != LK_ERROR_NONE)
+  if (lk_load_image(f->paths[(size_t)index].c_str(), &px, &r, &c) != LK_ERROR_NONE)
     return nullptr;
   lk_free_image(f->held[index & 1]);
   f->held[index & 1] = px;
@@ -51,7 +51,7 @@ int main(int argc, char **argv) {
   for (int i = 5; i < argc; ++i)
     frames.paths.push_back(argv[i]);
   uint8_t *probe = nullptr;
-  if (lk_load_pgm(frames.paths[0].c_str(), &probe, &frames.rows, &frames.cols) != LK_ERROR_NONE) {
+  if (lk_load_image(frames.paths[0].c_str(), &probe, &frames.rows, &frames.cols) != LK_ERROR_NONE) {
     std::fprintf(stderr, "cannot read %s\n", frames.paths[0].c_str());
     return 1;
   }
