@@ -7,5 +7,5 @@ name=$1; shift
 mkdir -p ../../build/tune
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -shared -std=c++17 -ffp-contract=off \
   -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -DLK_TUNE_ONLY_AFFINE_BICUBIC "$@" \
-  -o ../../build/tune/liblk_$name.so lk_engine.cpp lk_tracker.cpp lk_group.cpp lk_kernels.hip -lrocprofiler-sdk-roctx -lrccl
+  -o ../../build/tune/liblk_$name.so lk_engine.cpp lk_tracker.cpp lk_group.cpp lk_image_io.cpp lk_kernels.hip -lrocprofiler-sdk-roctx -lrccl -lz
 echo build/tune/liblk_$name.so
