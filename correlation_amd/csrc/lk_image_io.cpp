@@ -10,10 +10,13 @@
 //         + 16384) >> 15
 //   BMP   uncompressed 1 / 4 / 8-bit palette, 24 and 32 bits, bottom-up or top-down
 //   PNM   P1-P6 (maxval <= 255 as stored, 16-bit samples -> the high byte)
-//   BMP and PPM colour -> grey with OpenCV's 14-bit coefficients (4899 R + 9617 G + 1868 B + 8192) >> 14
-// Grey files decode exactly (tests/test_image_io.py compares with PIL's decoders); the two colour conversions are restated
-// from the libraries' documented formulas and are NOT pinned against OpenCV (it cannot be built or run here).  JPEG and
-// TIFF need libjpeg / libtiff headers this image lacks: LK_ERROR_BAD_DOMAIN, like every malformed or truncated file.
+//   TIFF  the container most cameras for image correlation write: either byte order, strips or tiles, 8 / 16-bit grey (either
+//         polarity), grey + alpha, RGB(A), 8-bit palette; uncompressed, PackBits, LZW, Deflate; horizontal differencing; first page
+//   BMP, PPM and TIFF colour -> grey with OpenCV's 14-bit coefficients (4899 R + 9617 G + 1868 B + 8192) >> 14
+// Grey files decode exactly (tests/test_image_io.py compares with PIL's decoders); the two colour conversions and the 16 -> 8
+// bit reduction (the high byte) are restated from the libraries' documented behaviour and are NOT pinned against OpenCV (it
+// cannot be built or run here).  JPEG needs libjpeg's headers, which this image lacks (and lossy frames are no input for
+// image correlation): LK_ERROR_BAD_DOMAIN, like BigTIFF, planar or float TIFF and every malformed or truncated file.
 // Every length in a file is checked against the bytes that are there before it is used (ASan/UBSan run of the corpus and
 // of truncated / bit-flipped copies: tests/test_image_io.py).
 #include "../../include/lk_tracker.h"
@@ -275,6 +278,261 @@ bool decode_bmp(const Bytes &f, Image &out) {
   return true;
 }
 
+// ---- TIFF --------------------------------------------------------------------------------------------------------
+// Baseline TIFF 6.0 plus what scientific cameras and PIL / libtiff write: either byte order, strips or tiles, 8 or 16 bits
+// per sample, grey (either polarity), grey + alpha, RGB(A), 8-bit palette; uncompressed, PackBits, LZW, Deflate; horizontal
+// differencing.  The first page only (as cv::imread).  Not: BigTIFF, planar RGB, JPEG-in-TIFF, float samples, 1 / 4-bit.
+struct TiffChunk {
+  std::vector<uint8_t> px; // decoded rows: `rows` x `row_bytes`
+};
+
+bool tiff_unpack_bits(const uint8_t *s, size_t n, uint8_t *d, size_t want) {
+  size_t i = 0, o = 0;
+  while (o < want && i < n) {
+    const int c = (int8_t)s[i++];
+    if (c >= 0) {
+      const size_t len = (size_t)c + 1;
+      if (i + len > n)
+        return false;
+      const size_t take = len < want - o ? len : want - o;
+      std::memcpy(d + o, s + i, take);
+      o += take;
+      i += len;
+    } else if (c != -128) {
+      if (i >= n)
+        return false;
+      const size_t len = (size_t)(1 - c), take = len < want - o ? len : want - o;
+      std::memset(d + o, s[i++], take);
+      o += take;
+    }
+  }
+  return o == want;
+}
+
+bool tiff_lzw(const uint8_t *s, size_t n, uint8_t *d, size_t want) {
+  struct Code {
+    uint16_t prefix;
+    uint8_t suffix, first;
+    uint32_t length;
+  };
+  std::vector<Code> t(4096);
+  for (int i = 0; i < 256; ++i)
+    t[(size_t)i] = Code{0, (uint8_t)i, (uint8_t)i, 1};
+  int next = 258, width = 9, prev = -1;
+  uint32_t acc = 0;
+  int have = 0;
+  size_t i = 0, o = 0;
+  while (o < want) {
+    while (have < width && i < n) {
+      acc = (acc << 8) | s[i++];
+      have += 8;
+    }
+    if (have < width)
+      break;
+    const int code = (int)((acc >> (have - width)) & ((1u << width) - 1u));
+    have -= width;
+    if (code == 256) {
+      next = 258, width = 9, prev = -1;
+      continue;
+    }
+    if (code == 257)
+      break;
+    if (prev < 0) {
+      if (code > 255)
+        return false;
+      d[o++] = (uint8_t)code;
+      prev = code;
+      continue;
+    }
+    if (code > next || (code >= 256 && code < 258))
+      return false;
+    // the string of `code`, or (code == next) the previous string + its own first byte
+    const int src = code < next ? code : prev;
+    const uint32_t len = t[(size_t)src].length + (code < next ? 0u : 1u);
+    const uint8_t first = t[(size_t)src].first;
+    const size_t end = o + len;
+    size_t at = end;
+    if (code == next) {
+      --at;
+      if (at < want)
+        d[at] = first;
+    }
+    for (int c = src; at > o; c = t[(size_t)c].prefix) { // back to front
+      --at;
+      if (at < want)
+        d[at] = t[(size_t)c].suffix;
+      if (t[(size_t)c].length == 1)
+        break;
+    }
+    o = end < want ? end : want;
+    if (next < 4096) {
+      t[(size_t)next] = Code{(uint16_t)prev, first, t[(size_t)prev].first, t[(size_t)prev].length + 1};
+      ++next;
+      if (next >= (1 << width) - 1 && width < 12) // (TIFF's early change)
+        ++width;
+    }
+    prev = code;
+  }
+  return o == want;
+}
+
+bool decode_tiff(const Bytes &f, Image &out) {
+  if (!f.has(0, 8))
+    return false;
+  const bool le = f.p[0] == 'I';
+  auto u16 = [&](size_t at) { return le ? f.le16(at) : ((uint32_t)f.p[at] << 8 | f.p[at + 1]); };
+  auto u32 = [&](size_t at) { return le ? f.le32(at) : f.be32(at); };
+  if (u16(2) != 42)
+    return false; // (43: BigTIFF)
+  const size_t ifd = u32(4);
+  if (!f.has(ifd, 2))
+    return false;
+  const size_t n_entries = u16(ifd);
+  if (!f.has(ifd + 2, n_entries * 12))
+    return false;
+  struct Entry {
+    uint32_t type = 0, count = 0;
+    size_t at = 0; // where the values are
+  };
+  auto find = [&](uint32_t tag, Entry &e) {
+    for (size_t i = 0; i < n_entries; ++i) {
+      const size_t at = ifd + 2 + 12 * i;
+      if (u16(at) != tag)
+        continue;
+      e.type = u16(at + 2);
+      e.count = u32(at + 4);
+      const size_t unit = e.type == 3 ? 2 : e.type == 4 ? 4 : e.type == 1 ? 1 : 0;
+      if (!unit || e.count == 0 || e.count > (1u << 28))
+        return false;
+      const size_t bytes = unit * (size_t)e.count;
+      e.at = bytes <= 4 ? at + 8 : (size_t)u32(at + 8);
+      return f.has(e.at, bytes);
+    }
+    return false;
+  };
+  auto value = [&](const Entry &e, size_t k) -> uint32_t { return e.type == 3 ? u16(e.at + 2 * k) : e.type == 4 ? u32(e.at + 4 * k) : f.p[e.at + k]; };
+  auto scalar = [&](uint32_t tag, uint32_t fallback) {
+    Entry e;
+    return find(tag, e) ? value(e, 0) : fallback;
+  };
+  const long long w = scalar(256, 0), h = scalar(257, 0);
+  const uint32_t spp = scalar(277, 1), compression = scalar(259, 1), photometric = scalar(262, 1), predictor = scalar(317, 1);
+  uint32_t bps = 1;
+  {
+    Entry e;
+    if (find(258, e)) {
+      bps = value(e, 0);
+      for (size_t k = 1; k < e.count && k < 8; ++k)
+        if (value(e, k) != bps)
+          return false;
+    }
+  }
+  if ((bps != 8 && bps != 16) || spp < 1 || spp > 4 || (spp > 1 && scalar(284, 1) != 1) || scalar(339, 1) != 1 || scalar(266, 1) != 1 ||
+      !(compression == 1 || compression == 5 || compression == 8 || compression == 32946 || compression == 32773) || predictor > 2 ||
+      photometric > 3 || (photometric == 2 && spp < 3) || (photometric == 3 && (spp != 1 || bps != 8)) || (photometric < 2 && spp > 2))
+    return false;
+  uint8_t pal_grey[256];
+  if (photometric == 3) {
+    Entry e;
+    if (!find(320, e) || e.type != 3 || e.count < 3 * 256)
+      return false;
+    for (size_t i = 0; i < 256; ++i)
+      pal_grey[i] = grey_opencv(value(e, i) >> 8, value(e, 256 + i) >> 8, value(e, 512 + i) >> 8);
+  }
+  if (w <= 0 || h <= 0 || w > (1 << 24) || h > (1 << 24) || w * h > kMaxPixels)
+    return false;
+  // strips (full-width chunks of rows_per_strip rows) or tiles
+  Entry offs, counts;
+  long long cw = w, chh;
+  const bool tiled = find(324, offs);
+  if (tiled) {
+    cw = scalar(322, 0), chh = scalar(323, 0);
+    if (!find(325, counts))
+      return false;
+  } else {
+    chh = scalar(278, 0xffffffffu);
+    if (!find(273, offs) || !find(279, counts))
+      return false;
+  }
+  if (chh > h && !tiled)
+    chh = h;
+  if (cw <= 0 || chh <= 0 || cw > (1 << 24) || chh > (1 << 24))
+    return false;
+  const long long across = (w + cw - 1) / cw, down = (h + chh - 1) / chh;
+  if ((long long)offs.count < across * down || (long long)counts.count < across * down)
+    return false;
+  const size_t sample_bytes = bps / 8, px_bytes = sample_bytes * spp, row_bytes = (size_t)cw * px_bytes;
+  // a file cannot hold more than its compression allows (LZW at most ~4096 : 1): refuse before allocating
+  if ((double)w * (double)h * (double)px_bytes > 4096.0 * (double)f.n + 65536.0 || !out.alloc(w, h))
+    return false;
+  std::vector<uint8_t> chunk;
+  for (long long cy = 0; cy < down; ++cy)
+    for (long long cx = 0; cx < across; ++cx) {
+      const size_t k = (size_t)(cy * across + cx);
+      const size_t at = value(offs, k), len = value(counts, k);
+      const long long rows = tiled ? chh : (chh < h - cy * chh ? chh : h - cy * chh);
+      const size_t want = (size_t)rows * row_bytes;
+      // (what `len` bytes can expand to: nothing / PackBits 64 : 1 / Deflate 1032 : 1 / LZW's longest strings)
+      const double most = compression == 1 ? 1.0 : compression == 32773 ? 64.0 : compression == 5 ? 4096.0 : 1032.0;
+      if (!f.has(at, len) || (double)want > most * (double)len + 64.0)
+        return false;
+      chunk.resize(want);
+      bool ok;
+      switch (compression) {
+      case 1:
+        ok = len >= want;
+        if (ok)
+          std::memcpy(chunk.data(), f.p + at, want);
+        break;
+      case 5: ok = tiff_lzw(f.p + at, len, chunk.data(), want); break;
+      case 32773: ok = tiff_unpack_bits(f.p + at, len, chunk.data(), want); break;
+      default: {
+        uLongf got = (uLongf)want;
+        const int rc = uncompress(chunk.data(), &got, f.p + at, (uLong)len);
+        ok = (rc == Z_OK || rc == Z_BUF_ERROR) && got == want;
+        break;
+      }
+      }
+      if (!ok)
+        return false;
+      for (long long r = 0; r < rows; ++r) {
+        const long long y = cy * chh + r;
+        if (y >= h)
+          break;
+        uint8_t *row = chunk.data() + (size_t)r * row_bytes;
+        if (predictor == 2) { // horizontal differencing, sample by sample, in the file's byte order
+          if (bps == 8) {
+            for (size_t i = px_bytes; i < row_bytes; ++i)
+              row[i] = (uint8_t)(row[i] + row[i - px_bytes]);
+          } else {
+            for (size_t i = px_bytes; i + 1 < row_bytes; i += 2) {
+              const size_t j = i - px_bytes;
+              const uint32_t a = le ? (uint32_t)row[i] | (uint32_t)row[i + 1] << 8 : (uint32_t)row[i] << 8 | row[i + 1];
+              const uint32_t b = le ? (uint32_t)row[j] | (uint32_t)row[j + 1] << 8 : (uint32_t)row[j] << 8 | row[j + 1];
+              const uint32_t v = (a + b) & 0xffffu;
+              row[i + (le ? 0 : 1)] = (uint8_t)v;
+              row[i + (le ? 1 : 0)] = (uint8_t)(v >> 8);
+            }
+          }
+        }
+        const size_t hi = bps == 16 && le ? 1 : 0; // where a sample's high byte sits
+        uint8_t *dst = out.px + (size_t)y * (size_t)w;
+        for (long long x = 0; x < cw && cx * cw + x < w; ++x) {
+          const uint8_t *p = row + (size_t)x * px_bytes + hi;
+          uint8_t g;
+          if (photometric == 3)
+            g = pal_grey[p[0]];
+          else if (photometric == 2)
+            g = grey_opencv(p[0], p[sample_bytes], p[2 * sample_bytes]);
+          else
+            g = photometric == 0 ? (uint8_t)(255 - p[0]) : p[0];
+          dst[cx * cw + x] = g;
+        }
+      }
+    }
+  return true;
+}
+
 // ---- PNM ---------------------------------------------------------------------------------------------------------
 bool decode_pnm(const Bytes &f, Image &out) {
   const int kind = f.p[1] - '0';
@@ -368,6 +626,8 @@ int lk_decode_image(const uint8_t *bytes, size_t n, uint8_t **pixels, int *rows,
       ok = decode_bmp(f, img);
     else if (n >= 3 && bytes[0] == 'P' && bytes[1] >= '1' && bytes[1] <= '6')
       ok = decode_pnm(f, img);
+    else if (n >= 4 && ((bytes[0] == 'I' && bytes[1] == 'I') || (bytes[0] == 'M' && bytes[1] == 'M')))
+      ok = decode_tiff(f, img);
   } catch (...) { // (out of memory in a scratch vector)
     ok = false;
   }

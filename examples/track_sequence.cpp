@@ -4,9 +4,9 @@
 //
 //   g++ -std=c++17 -O2 -Iinclude examples/track_sequence.cpp -Lcorrelation_amd -llk_engine
 //       -Wl,-rpath,$PWD/correlation_amd -o track_sequence          (one command line)
-//   ./track_sequence report.csv eulerian|lagrangian|strict  hs vs  frame0.pgm frame1.pgm [frame2.pgm ...]
+//   ./track_sequence report.csv eulerian|lagrangian|strict  hs vs  frame0.tif frame1.tif [frame2.tif ...]
 //
-// Frames are whatever lk_load_image decodes (PNG, BMP, PNM) - the 8-bit grey cv::imread(path, IMREAD_GRAYSCALE) would give.  The rectangular domain is the image minus a 24-pixel margin, split
+// Frames are whatever lk_load_image decodes (PNG, TIFF, BMP, PNM) - the 8-bit grey cv::imread(path, IMREAD_GRAYSCALE) would give.  The rectangular domain is the image minus a 24-pixel margin, split
 // into hs x vs sectors; affine model, bicubic interpolation, pyramid levels 0/1/2, zero global guess.
 #include <cstdio>
 #include <cstdlib>

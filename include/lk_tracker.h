@@ -157,9 +157,10 @@ void lk_free_image(uint8_t *pixels);
 /* What cv::imread(path, cv::IMREAD_GRAYSCALE) hands the reference (manager_class.cpp:102-107,174,211,250;
  * cuda_class.cu:484-510; the reference's sample frames are PNG, mainapp.cpp:384-408): the file decoded to
  * 8-bit grey, rows x cols, row-major, malloc'ed (lk_free_image).  PNG (all colour types and depths, Adam7),
- * uncompressed BMP, PNM P1-P6; 16-bit samples give their high byte, colour is converted with the fixed-point
+ * TIFF (strips or tiles, either byte order, 8 / 16 bits, uncompressed / PackBits / LZW / Deflate, horizontal
+ * differencing; first page), uncompressed BMP, PNM P1-P6; 16-bit samples give their high byte, colour is converted with the fixed-point
  * coefficients of the decoder OpenCV uses for that container (csrc/lk_image_io.cpp has the formulas and what
- * is pinned).  LK_ERROR_BAD_DOMAIN for a missing, malformed, truncated or unsupported (JPEG, TIFF) file;
+ * is pinned).  LK_ERROR_BAD_DOMAIN for a missing, malformed, truncated or unsupported (JPEG, BigTIFF) file;
  * *pixels is NULL then.  Thread-safe; lk_decode_image is the same for a file already in memory. */
 int lk_load_image(const char *path, uint8_t **pixels, int *rows, int *cols);
 int lk_decode_image(const uint8_t *bytes, size_t n_bytes, uint8_t **pixels, int *rows, int *cols);

@@ -146,6 +146,90 @@ def corpus():
     bits = rng.integers(0, 2, (5, 11), dtype=np.uint8)
     files["bitmap.pbm"] = (b"P4\n11 5\n" + np.packbits(bits, axis=1).tobytes(), ((1 - bits) * 255).astype(np.uint8))
     files["ascii.pbm"] = (b"P1\n# c\n11 5\n" + "".join(str(v) for v in bits.reshape(-1)).encode(), ((1 - bits) * 255).astype(np.uint8))
+    # TIFF: libtiff's encoders through PIL (strips; every compression, with and without horizontal differencing) ...
+    g8b = np.ascontiguousarray(g8[:, :50])
+    for comp in (None, "packbits", "tiff_lzw", "tiff_adobe_deflate"):
+        pil(f"pil_grey8_{comp}.tif", PIL.fromarray(g8b), "TIFF", g8b, compression=comp)
+    for comp in ("tiff_lzw", "tiff_adobe_deflate"):
+        pil(f"pil_grey8_{comp}_pred.tif", PIL.fromarray(g8b), "TIFF", g8b, compression=comp, tiffinfo={317: 2})
+        pil(f"pil_grey16_{comp}_pred.tif", PIL.fromarray(g16), "TIFF", (g16 >> 8).astype(np.uint8), compression=comp, tiffinfo={317: 2})
+        pil(f"pil_rgb_{comp}_pred.tif", PIL.fromarray(rgb), "TIFF", grey_opencv(rgb), compression=comp, tiffinfo={317: 2})
+    smooth = (np.add.outer(np.arange(300), np.arange(200)) // 3 % 256).astype(np.uint8)   # (long LZW strings, several strips)
+    pil("pil_smooth_lzw.tif", PIL.fromarray(smooth), "TIFF", smooth, compression="tiff_lzw")
+    noise = rng.integers(0, 256, (120, 90), dtype=np.uint8)                               # (the LZW table fills up and is cleared)
+    pil("pil_noise_lzw.tif", PIL.fromarray(noise), "TIFF", noise, compression="tiff_lzw")
+    pil("pil_grey16.tif", PIL.fromarray(g16), "TIFF", (g16 >> 8).astype(np.uint8))
+    pil("pil_rgb.tif", PIL.fromarray(rgb), "TIFF", grey_opencv(rgb))
+    pil("pil_rgba_lzw.tif", PIL.fromarray(rgba), "TIFF", grey_opencv(rgb), compression="tiff_lzw")
+    pil("pil_palette.tif", p, "TIFF", grey_opencv(pal[idx]))
+    pil("pil_grey_alpha.tif", PIL.fromarray(la), "TIFF", g8)
+
+    # ... and by hand: big endian, tiles, white-is-zero, 16-bit differencing in both byte orders
+    def tiff_bytes(samples, bps, photometric, big_endian=False, tile=None, predictor=1):
+        h, w, ch = samples.shape
+        e = ">" if big_endian else "<"
+        dt = np.dtype(f"{e}u2") if bps == 16 else np.dtype(np.uint8)
+
+        def encode(block):   # (rows, cols, ch) -> bytes, with the differencing applied
+            b = block.astype(np.int64)
+            if predictor == 2:
+                b[:, 1:] = (b[:, 1:] - block[:, :-1]) % (1 << bps)
+            return b.astype(dt).tobytes()
+
+        if tile:
+            th, tw = tile
+            chunks = []
+            for y in range(0, h, th):
+                for x in range(0, w, tw):
+                    blk = np.zeros((th, tw, ch), np.int64)
+                    part = samples[y:y + th, x:x + tw]
+                    blk[:part.shape[0], :part.shape[1]] = part
+                    chunks.append(encode(blk))
+        else:
+            rps = 3
+            chunks = [encode(samples[y:y + rps]) for y in range(0, h, rps)]
+        entries = {256: (3, [w]), 257: (3, [h]), 258: (3, [bps] * ch), 259: (3, [1]), 262: (3, [photometric]), 277: (3, [ch]), 317: (3, [predictor])}
+        n = len(chunks)
+        data_at = 8
+        offsets, at = [], data_at
+        for c in chunks:
+            offsets.append(at)
+            at += len(c)
+        if tile:
+            entries.update({322: (3, [tile[1]]), 323: (3, [tile[0]]), 324: (4, offsets), 325: (4, [len(c) for c in chunks])})
+        else:
+            entries.update({278: (3, [3]), 273: (4, offsets), 279: (4, [len(c) for c in chunks])})
+        ifd_at = at + (at & 1)
+        body = b"".join(chunks) + (b"\0" if at & 1 else b"")
+        extra_at = ifd_at + 2 + 12 * len(entries) + 4
+        ifd, extra = struct.pack(e + "H", len(entries)), b""
+        for tag in sorted(entries):
+            typ, vals = entries[tag]
+            fmt = "H" if typ == 3 else "I"
+            raw = struct.pack(e + fmt * len(vals), *vals)
+            if len(raw) <= 4:
+                field = raw + bytes(4 - len(raw))
+            else:
+                field = struct.pack(e + "I", extra_at + len(extra))
+                extra += raw + bytes(len(raw) & 1)
+            ifd += struct.pack(e + "HHI", tag, typ, len(vals)) + field
+        ifd += struct.pack(e + "I", 0)
+        return (b"MM\0*" if big_endian else b"II*\0") + struct.pack(e + "I", ifd_at) + body + ifd + extra
+
+    for big in (False, True):
+        tag = "be" if big else "le"
+        s8 = rng.integers(0, 256, (10, 13, 1))
+        s16 = rng.integers(0, 65536, (10, 13, 1))
+        c16 = rng.integers(0, 65536, (7, 9, 3))
+        files[f"own_grey8_{tag}.tif"] = (tiff_bytes(s8, 8, 1, big), s8[..., 0].astype(np.uint8))
+        files[f"own_grey8_white_is_zero_{tag}.tif"] = (tiff_bytes(s8, 8, 0, big), (255 - s8[..., 0]).astype(np.uint8))
+        files[f"own_grey16_{tag}.tif"] = (tiff_bytes(s16, 16, 1, big), (s16[..., 0] >> 8).astype(np.uint8))
+        files[f"own_grey16_pred_{tag}.tif"] = (tiff_bytes(s16, 16, 1, big, predictor=2), (s16[..., 0] >> 8).astype(np.uint8))
+        files[f"own_rgb16_pred_{tag}.tif"] = (tiff_bytes(c16, 16, 2, big, predictor=2), grey_opencv(c16 >> 8))
+        files[f"own_grey8_tiles_{tag}.tif"] = (tiff_bytes(s8, 8, 1, big, tile=(16, 16)), s8[..., 0].astype(np.uint8))
+        files[f"own_grey16_tiles_pred_{tag}.tif"] = (tiff_bytes(s16, 16, 1, big, tile=(16, 16), predictor=2), (s16[..., 0] >> 8).astype(np.uint8))
+        wide = rng.integers(0, 256, (40, 37, 1))
+        files[f"own_grey8_many_tiles_{tag}.tif"] = (tiff_bytes(wide, 8, 1, big, tile=(16, 16)), wide[..., 0].astype(np.uint8))
     # BMP by hand: top-down 32-bit and a 4-bit palette image
     bgra = rng.integers(0, 256, (5, 7, 4), dtype=np.uint8)
     hdr = struct.pack("<IiiHHIIiiII", 40, 7, -5, 1, 32, 0, 0, 0, 0, 0, 0)
@@ -164,7 +248,7 @@ def files():
 
 
 def test_every_container_decodes_to_the_expected_grey(engine_lib, files):
-    assert len(files) > 100
+    assert len(files) > 150
     for name, (data, expect) in files.items():
         got = tk.decode_image(data, engine_lib)
         assert got.dtype == np.uint8 and got.shape == expect.shape, name
@@ -172,7 +256,9 @@ def test_every_container_decodes_to_the_expected_grey(engine_lib, files):
 
 
 def test_grey_files_equal_pils_own_decoders(engine_lib, files):
-    for name in ("pil_grey8.png", "pil_grey8_optimized.png", "pil_grey_alpha.png", "pil_1bit.png", "pil_grey8.bmp", "pil_grey8.pgm", "pil_1bit.bmp"):
+    for name in ("pil_grey8.png", "pil_grey8_optimized.png", "pil_grey_alpha.png", "pil_1bit.png", "pil_grey8.bmp", "pil_grey8.pgm", "pil_1bit.bmp",
+                 "pil_grey8_None.tif", "pil_grey8_packbits.tif", "pil_grey8_tiff_lzw.tif", "pil_grey8_tiff_adobe_deflate_pred.tif",
+                 "pil_smooth_lzw.tif", "pil_noise_lzw.tif", "own_grey8_tiles_be.tif", "own_grey8_many_tiles_le.tif"):
         ours = tk.decode_image(files[name][0], engine_lib)
         theirs = np.asarray(PIL.open(io.BytesIO(files[name][0])).convert("L"))
         assert np.array_equal(ours, theirs), name
@@ -197,7 +283,9 @@ def test_malformed_files_are_refused_not_guessed(engine_lib, files, tmp_path):
         "missing file": None,
         "empty": b"",
         "jpeg": b"\xff\xd8\xff\xe0" + bytes(64),
-        "tiff": b"II*\x00" + bytes(64),
+        "tiff without an image": b"II*\x00" + bytes(64),
+        "bigtiff": b"II+\x00" + bytes(64),
+        "tiff with float samples": files["own_grey16_le.tif"][0].replace(struct.pack("<HHIHH", 317, 3, 1, 1, 0), struct.pack("<HHIHH", 339, 3, 1, 3, 0)),
         "truncated png": png[:len(png) // 2],
         "png without IEND": png[:-12],
         "bad crc": png[:40] + bytes([png[40] ^ 1]) + png[41:],
