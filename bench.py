@@ -1081,7 +1081,7 @@ def main():
                                                                if (not strong and measured_clock_hz("one_pair_C2")) else None),
                          "measured_clock_GHz": (measured_clock_hz("one_pair_C2") or 0) / 1e9 or None,
                          "valu_issue_frac_is": "SQ_INSTS_VALU per launch (profile constant) x 2 cycles / (1024 SIMDs x 2.4 GHz x kernel_ms) - beside it the same at the clock the traced "
-                                               "wavefronts ran at (profiles/r03_wave_timeline.txt): "
+                                               "wavefronts ran at (`measured_clock_GHz`, from profiles/r0N_wave_timeline.txt through the traffic file named above): "
                                                "the binding limit of this kernel is VALU issue and the critical path of its slowest sectors, not HBM",
                          "measured": "K back-to-back solve launches of the engine and stream the timed region ran on, "
                                      "between two HIP events on that stream",
