@@ -91,6 +91,35 @@ def test_window_records_are_the_one_pair_loops_bytes(frames448, mode, kind):
     b.close()
 
 
+@pytest.mark.parametrize("pyramid", [(1, 1, 2), (0, 2, 2), (0, 1, 0), (0, 1, 3)], ids=lambda t: "levels_%d_%d_%d" % t)
+@pytest.mark.parametrize("interpolation", [ca.IM_BICUBIC, ca.IM_BILINEAR, ca.IM_NEAREST], ids=["bicubic", "bilinear", "nearest"])
+def test_window_bytes_on_other_pyramids_and_interpolators(frames448, pyramid, interpolation):
+    """levels that stop above the image, skip a level, are the image alone, or go one level deeper; the two cheaper samplers:
+    the window's frames still are the loop's bytes (batch-invariant mode; the mixed domain: every group width at once)"""
+    if interpolation != ca.IM_BICUBIC and pyramid != (0, 1, 2) and pyramid != (1, 1, 2):
+        pytest.skip("the samplers are crossed with one other pyramid only")
+    frames, n, c = frames448, 5, (223.5, 223.5)
+    engines = []
+    for _ in range(2):
+        e = ca.HipCorrelationEngine(interpolation=interpolation, py_start=pyramid[0], py_step=pyramid[1], py_stop=pyramid[2])
+        e.set_batch_invariant(True)
+        e.set_undeformed_image(frames[0])
+        domain(e, "mixed", 448)
+        engines.append(e)
+    a, b = engines
+    g_loop, r_loop = loop(a, frames, 0, n, center=c)
+    b.sequence_reserve(n)
+    g_win, r_win = window(b, frames, 0, n, center=c)
+    assert (r_loop["error_code"] == 0).mean() > 0.5
+    assert g_win.tobytes() == g_loop.tobytes() and r_win.tobytes() == r_loop.tobytes()
+    # ... and the state the window leaves is the loop's: one more pair through the one-pair path on both
+    g_a, r_a = loop(a, frames, n, 1, center=c)
+    g_b, r_b = loop(b, frames, n, 1, center=c)
+    assert g_a.tobytes() == g_b.tobytes() and r_a.tobytes() == r_b.tobytes()
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("mode", ["reference_order:1", "batch_invariant"])
 def test_windows_chain_like_the_loop(frames448, mode):
     """3 + 1 + 3 frames in three windows (ring slots reused), then a one-pair solve: the sequence state a window leaves
