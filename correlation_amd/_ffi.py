@@ -163,6 +163,7 @@ SYMBOLS = {
     "lk_group_sequence_set_frames_device": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "lk_group_correlate_sequence_async": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "lk_group_wait_sequence": (C.c_int, [_P, _P]),
+    "lk_group_sequence_records": (C.c_int, [_P, _P]),
     "lk_group_sequence_records_device": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
     "lk_group_probe_overlap": (C.c_int, [_P, C.c_int, _F]),
     "lk_group_records_device": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),

@@ -82,6 +82,7 @@ struct Member {
   lk_result *d_seq_rec = nullptr, *d_seq_all = nullptr; // windows: [frames][cap] of this member, [n][frames][cap] of everybody
   size_t seq_frames_cap = 0;
   int seq_frames = 0; // frames of the outstanding window (0: none)
+  int exchanged_frames = 0; // frames of the window whose records the last exchange gathered into d_seq_all (0: none)
   float *d_guess = nullptr;   // [cap][6]
   lk_result *d_rec = nullptr; // [cap] this member's block (padded)
   lk_result *d_all = nullptr; // [n][cap] everybody's blocks
@@ -945,8 +946,41 @@ int lk_group_wait_sequence(lk_group *g, lk_result *out) {
       return LK_ERROR_NONE;
     }();
     me.seq_frames = 0;
-    return gather_records(g, me, me.d_seq_rec, me.d_seq_all, block, frames, rc, out);
+    me.exchanged_frames = 0;
+    const int grc = gather_records(g, me, me.d_seq_rec, me.d_seq_all, block, frames, rc, out);
+    if (!grc)
+      me.exchanged_frames = frames;
+    return grc;
   }, true);
+}
+
+// The records of the window that lk_group_wait_sequence(g, NULL) last exchanged, fetched separately: waits for THAT exchange
+// only, so that the next window - launched in between - is solved while the records travel (between the devices and down to
+// the host).  The reference's loop has the frame k + 1 upload behind the solve of pair k (manager_class.cpp:1438-1447); this is
+// the same for the way back.
+int lk_group_sequence_records(lk_group *g, lk_result *out) {
+  if (!g || !out)
+    return LK_ERROR_BAD_DOMAIN;
+  for (const Member &me : g->m)
+    if (me.exchanged_frames < 1 || !me.gathered_valid)
+      return g->fail(LK_ERROR_BAD_DOMAIN, "lk_group_sequence_records: no exchanged window (lk_group_wait_sequence(g, NULL) first)");
+  const int n = (int)g->m.size();
+  return g->run([=](Member &me) -> int {
+    const int frames = me.exchanged_frames;
+    const size_t block = (size_t)frames * (size_t)g->cap * sizeof(lk_result);
+    GHIP(hipEventSynchronize(me.ev_gathered)); // (every member: the exchange is complete on all devices when this returns)
+    if (me.rank != 0)
+      return LK_ERROR_NONE;
+    hipStream_t cs = comm_stream(me);
+    for (int q = 0; q < n; ++q) { // global sector order: block q starts at rank q's first sector
+      int first, count;
+      shard(g->S, q, n, first, count);
+      GHIP(hipMemcpy2DAsync(out + first, (size_t)g->S * sizeof(lk_result), (const char *)me.d_seq_all + (size_t)q * block,
+                            (size_t)g->cap * sizeof(lk_result), (size_t)count * sizeof(lk_result), (size_t)frames, hipMemcpyDeviceToHost, cs));
+    }
+    GHIP(hipStreamSynchronize(cs));
+    return LK_ERROR_NONE;
+  });
 }
 
 int lk_group_sequence_records_device(lk_group *g, int rank, const void **d_records) {

@@ -145,6 +145,15 @@ class HipCorrelationGroup:
     def wait_sequence(self, fetch=True):
         out = np.zeros((self._seq_frames, self.n_sectors), _ffi.RESULT_DTYPE) if fetch else None
         self._chk(self.lib.lk_group_wait_sequence(self._h, out.ctypes.data_as(C.c_void_p) if fetch else None))
+        self._exchanged_frames = self._seq_frames
+        return out
+
+    def sequence_records(self):
+        """the records of the window wait_sequence(fetch=False) last exchanged ([frames][S]); waits for that exchange only -
+        call it after launching the next window and the records travel while that one is solved"""
+        n = getattr(self, "_exchanged_frames", 0)   # (0: no window exchanged yet - the library says so)
+        out = np.zeros((max(n, 1), self.n_sectors), _ffi.RESULT_DTYPE)
+        self._chk(self.lib.lk_group_sequence_records(self._h, out.ctypes.data_as(C.c_void_p)))
         return out
 
     def probe_overlap(self, rank=0):

@@ -126,6 +126,11 @@ int lk_group_correlate_sequence_async(lk_group *g, int und_slot, int first_slot,
  * member) and hands them over in global sector order: out [n_frames][S] host records, or NULL = leave them on the
  * devices (lk_group_sequence_records_device; lk_group_synchronize waits for the exchange) */
 int lk_group_wait_sequence(lk_group *g, lk_result *out);
+/* The records of the window lk_group_wait_sequence(g, NULL) last exchanged, out [n_frames][S] in global sector order.
+ * Waits for that exchange only: call it AFTER launching the next window (lk_group_correlate_sequence_async) and the
+ * records of window w travel - between the devices and down to the host - while window w + 1 is solved.  Must be
+ * called before the next lk_group_wait_sequence (which gathers into the same buffers). */
+int lk_group_sequence_records(lk_group *g, lk_result *out);
 int lk_group_sequence_records_device(lk_group *g, int rank, const void **d_records);
 /* what overlapped on `rank`'s device (HIP event times, ms): [0] duration of the last frame transfer on the
  * communication stream, [1] of the last solve / window on the solve stream, [2] transfer begin - solve begin,

@@ -310,3 +310,56 @@ def test_group_windows_equal_one_engine_and_transfers_overlap_the_solve(mode):
     r1 = g.correlate_all(None)
     assert r1.tobytes() == want[1].tobytes()
     g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["batch_invariant", "reference_order"])
+def test_group_window_records_fetched_behind_the_next_window(mode):
+    """lk_group_sequence_records: window w's records are exchanged and downloaded while window w + 1 is being solved
+    (wait_sequence without a fetch -> launch the next window -> fetch).  Three windows on three ranks of one device; the
+    bytes are ONE engine's pair-by-pair loop, and a fetch without an exchanged window is refused."""
+    K, n_ranks, W = 3, 3, 3
+    frames = ca.speckle.speckle_sequence(512, 512, W * K + 1, velocity=(0.8, -0.4), dilation=2e-4, seed=11)
+    c, zero = (255.5, 255.5), np.zeros(6, np.float32)
+
+    def setup(fn):
+        fn("lk_set_batch_invariant", 1) if mode == "batch_invariant" else fn("lk_set_reference_order", 1)
+
+    e = ca.HipCorrelationEngine()
+    setup(lambda name, v: getattr(e.lib, name)(e._h, v))
+    e.set_undeformed_image(frames[0])
+    e.set_rect_grid(24.0, 24.0, 487.0, 487.0, 40, 37)
+    e.commit_sectors()
+    want = []
+    for k in range(W * K):
+        e.set_deformed_image(frames[k + 1])
+        e.adjust_initial_guess(k, True, zero, c)
+        want.append(e.correlate_all(None))
+    want = np.stack(want)
+    e.close()
+
+    g = ca.HipCorrelationGroup([0] * n_ranks)
+    setup(g.for_each_engine)
+    g.set_image(ca.IMG_UND, frames[0])
+    g.set_rect_grid(24.0, 24.0, 487.0, 487.0, 40, 37)
+    g.commit_sectors()
+    g.sequence_reserve(2 * K)
+    with pytest.raises(ca.LkError):
+        g.sequence_records()
+    got = []
+    g.sequence_set_frames(0, frames[1:K + 1])
+    g.adjust_initial_guess(0, True, zero, c)
+    g.correlate_sequence_async(K, first_slot=0)
+    for w in range(W):
+        if w + 1 < W:   # the next window's frames into the other half of the ring, behind the running solve
+            g.sequence_set_frames(((w + 1) % 2) * K, frames[(w + 1) * K + 1:(w + 2) * K + 1])
+        g.wait_sequence(fetch=False)               # window w is solved everywhere, its exchange is on its way
+        if w + 1 < W:
+            g.adjust_initial_guess((w + 1) * K, True, zero, c)
+            g.correlate_sequence_async(K, first_slot=((w + 1) % 2) * K)
+        got.append(g.sequence_records())           # ... and arrives while window w + 1 runs
+    got = np.concatenate(got)
+    g.close()
+    assert got.shape == want.shape
+    for k in range(W * K):
+        assert got[k].tobytes() == want[k].tobytes(), f"pair {k}"
