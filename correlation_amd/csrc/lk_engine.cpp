@@ -1289,8 +1289,9 @@ static int classify_sectors(lk_engine *e) {
         else if (e->h_class[(size_t)s] == kTeamClass)
           s_team += level0_count(e, s);
       }
-      // (the team is ONE critical path and pays its all-to-all per evaluation: a quarter more than its share of the samples)
-      int share = f ? std::atoi(f) : (int)(1250.0 * s_team / (s_team + s_one) + 0.5);
+      // (its share of the samples.  Round 3 gave the team a quarter more for its all-to-all; with round 4's kernels config 3
+      // measures 72 / 80 / 88 / 96 / 104 team workgroups -> 0.595 / 0.568 / 0.580 / 0.597 / 0.620 ms: 80 = the plain share)
+      int share = f ? std::atoi(f) : (int)(1000.0 * s_team / (s_team + s_one) + 0.5);
       e->team_share_permille = std::min(std::max(share, 250), 750);
       std::stable_sort(e->h_order.begin() + e->class_begin[cb], e->h_order.begin() + e->class_begin[cb + 1],
                        [&](uint32_t x, uint32_t y) { return level0_count(e, (int)x) > level0_count(e, (int)y); });
