@@ -49,6 +49,8 @@ for name, mode, ref, report, host_rebuild in (
         ("lagrangian/previous", tk.DEF_LAGRANGIAN, tk.REF_PREVIOUS, False, False),
         ("strict_lagrangian/previous", tk.DEF_STRICT_LAGRANGIAN, tk.REF_PREVIOUS, False, False),
         ("strict_lagrangian/previous, lists rebuilt on the host", tk.DEF_STRICT_LAGRANGIAN, tk.REF_PREVIOUS, False, True)):
+    if os.environ.get("LK_ONLY_FIRST") and name != "eulerian/first":   # (tuning runs: the windowed loop alone)
+        continue
     os.environ["LK_HOST_REWARP"] = "1" if host_rebuild else "0"
     e = ca.HipCorrelationEngine(fitting_model=wl.model, py_stop=wl.py_stop)
     t = tk.SequenceTracker(wl.model, tk.DOMAIN_RECT, mode, ref, tk.ERRMODE_CONTINUE, lib=e.lib)
