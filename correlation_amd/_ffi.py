@@ -104,6 +104,7 @@ SYMBOLS = {
     "lk_get_sequence_results_device": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "lk_sequence_is_pipelined": (C.c_int, [_P]),
     "lk_sequence_host_records": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
+    "lk_sequence_prepare_host_records": (C.c_int, [_P, C.c_int]),
     "lk_copy_sequence_records_device": (C.c_int, [_P, _P, C.c_size_t]),
     "lk_get_sequence_guesses": (C.c_int, [_P, _F]),
     "lk_adjust_initial_guess": (C.c_int, [_P, C.c_int, C.c_int, _F, C.c_float, C.c_float]),

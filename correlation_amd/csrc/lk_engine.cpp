@@ -3065,6 +3065,29 @@ static int launch_window(lk_engine *e, bool force_safe_flavour) {
   return LK_ERROR_NONE;
 }
 
+// one of the two alternating pinned record buffers of the windows, at least `need` records
+static int ensure_host_records(lk_engine *e, int b, size_t need) {
+  if (e->h_seq_results_n[b] >= need)
+    return LK_ERROR_NONE;
+  if (e->h_seq_results[b])
+    HIPCHK(hipHostFree(e->h_seq_results[b]));
+  e->h_seq_results[b] = nullptr;
+  e->h_seq_results_n[b] = 0;
+  HIPCHK(hipHostMalloc((void **)&e->h_seq_results[b], need * sizeof(lk_result), hipHostMallocDefault));
+  e->h_seq_results_n[b] = need;
+  return LK_ERROR_NONE;
+}
+
+int lk_sequence_prepare_host_records(lk_engine *e, int n_frames) {
+  if (!e || n_frames < 1)
+    return LK_ERROR_BAD_DOMAIN;
+  if (!e->committed)
+    return e->fail(LK_ERROR_BAD_DOMAIN, "sectors are not committed (call lk_commit_sectors)");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  // (the buffer the running window's records go to - h_seq_cur - is not touched: this is the other one, which the next launch takes)
+  return ensure_host_records(e, e->h_seq_cur ^ 1, (size_t)n_frames * (size_t)e->S);
+}
+
 int lk_correlate_sequence_async(lk_engine *e, int und_slot, int first_slot, int n_frames, int reference_previous,
                                 int constant_velocity, int flags) {
   if (!e)
@@ -3140,15 +3163,8 @@ int lk_correlate_sequence_async(lk_engine *e, int und_slot, int first_slot, int 
   std::memset(e->h_seq_flags, 0, 4 * sizeof(uint32_t));
   if (w.want_host) {
     e->h_seq_cur ^= 1;
-    const int b = e->h_seq_cur;
-    if (e->h_seq_results_n[b] < (size_t)n_frames * (size_t)S) {
-      if (e->h_seq_results[b])
-        HIPCHK(hipHostFree(e->h_seq_results[b]));
-      e->h_seq_results[b] = nullptr;
-      e->h_seq_results_n[b] = 0;
-      HIPCHK(hipHostMalloc((void **)&e->h_seq_results[b], (size_t)n_frames * (size_t)S * sizeof(lk_result), hipHostMallocDefault));
-      e->h_seq_results_n[b] = (size_t)n_frames * (size_t)S;
-    }
+    if (int hrc = ensure_host_records(e, e->h_seq_cur, (size_t)n_frames * (size_t)S))
+      return hrc;
   }
   if (!e->ev_seq)
     HIPCHK(hipEventCreateWithFlags(&e->ev_seq, hipEventDisableTiming));

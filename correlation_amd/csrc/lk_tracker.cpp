@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <charconv>
 #include <condition_variable>
@@ -937,9 +938,17 @@ int lk_sequence_run(lk_engine *e, lk_tracker *t, int n_frames, lk_frame_provider
     auto verify = [&]() { // (check mode) what the device solved from is what the tracker would have sent
       return !check || std::memcmp(device_guesses.data(), guesses.data(), device_guesses.size() * sizeof(float)) == 0;
     };
+    static const bool timing_env = [] { const char *f = std::getenv("LK_SEQ_TIMING"); return f && std::atoi(f) != 0; }(); // tuning: where the set-up goes
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+      if (timing_env)
+        std::fprintf(stderr, "lk_sequence_run: %8.3f ms  %s\n",
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), what);
+    };
     rc = lk_tracker_begin_frame(t, 0, cmds.data(), guesses.data());
     if (!rc)
       rc = register_sectors(e, t, cmds);
+    mark("sectors registered and committed");
     // Windows of K pairs (LK_SEQ_WINDOW, default 16; 1 = pair by pair, below): the K deformed frames of a window are
     // resident in the engine's ring and ONE launch per size class solves them all, every sector moving on to its next
     // frame as soon as its own previous frame is done (lk_correlate_sequence_async) - the guess of pair k + 1 needs
@@ -965,8 +974,20 @@ int lk_sequence_run(lk_engine *e, lk_tracker *t, int n_frames, lk_frame_provider
         frame_name[(size_t)f] = fr.name;
         return lk_sequence_set_frame(e, (f - 1) % R, fr.px, fr.rows, fr.cols, fr.step);
       };
+      mark("ring reserved, frame 1 in");
+      // (page-locking a window's record buffer takes milliseconds: the first one beside the first window's uploads, the
+      // second one beside the first window's solve - see the uploads of the next window below)
+      std::future<int> records_ready;
+      if (!rc)
+        records_ready = std::async(std::launch::async, [&] { return lk_sequence_prepare_host_records(e, K); });
       for (int f = 2; f <= K && !rc; ++f)
         rc = upload(f);
+      if (records_ready.valid()) {
+        const int prc = records_ready.get();
+        if (!rc)
+          rc = prc;
+      }
+      mark("first window's frames uploaded");
       // (the records of a window stay where the engine's copy left them: its pinned host buffers alternate, so window w's are
       // still there while window w + 1 is solved - and gone when window w + 2 is launched: the bookkeeping of w runs before that)
       const lk_result *win[2] = {nullptr, nullptr};
@@ -1022,7 +1043,7 @@ int lk_sequence_run(lk_engine *e, lk_tracker *t, int n_frames, lk_frame_provider
         if (!rc && first + K < pairs) {
           const int f_begin = first + K + 1, f_end = std::min(first + 2 * K, pairs);
           next = std::async(std::launch::async, [&, f_begin, f_end] {
-            int r = LK_ERROR_NONE;
+            int r = lk_sequence_prepare_host_records(e, std::min(K, pairs - (f_begin - 1))); // (the next window's; a no-op from the third window on)
             for (int f = f_begin; f <= f_end && !r; ++f)
               r = upload(f);
             return r;
@@ -1036,6 +1057,7 @@ int lk_sequence_run(lk_engine *e, lk_tracker *t, int n_frames, lk_frame_provider
             rc = wrc;
           if (!rc)
             rc = lk_sequence_host_records(e, &win[buf]);
+          mark("window solved, records on the host");
         }
         if (!rc && check)
           rc = lk_get_sequence_guesses(e, win_guess[buf].data());
@@ -1051,6 +1073,7 @@ int lk_sequence_run(lk_engine *e, lk_tracker *t, int n_frames, lk_frame_provider
         (void)next.get();
       if (!rc && have_n > 0)
         rc = bookkeeping();
+      mark("last window's bookkeeping done");
       return rc;
     }
     if (!rc)

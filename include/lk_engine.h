@@ -324,6 +324,11 @@ int lk_wait_sequence(lk_engine *e, lk_result *out);
  * alternate, so the pointer stays valid while the NEXT window is launched and solved (until the launch after that): a
  * frame loop digests window w while window w + 1 runs (lk_sequence_run) */
 int lk_sequence_host_records(lk_engine *e, const lk_result **records);
+/* page-locks, ahead of time, the record buffer the NEXT lk_correlate_sequence_async(..., flags & 1) of up to n_frames will
+ * use (locking the 38 MB of a 16-pair window of 50 176 sectors takes 7 ms; the launch does it itself otherwise).  May be
+ * called from another thread than the one that launches and waits, between a launch and the next one - a frame loop does
+ * it beside its uploads and beside the running window (lk_sequence_run). */
+int lk_sequence_prepare_host_records(lk_engine *e, int n_frames);
 /* the window's records [n_frames][S] and (flags & 2) guesses [n_frames][S][6] in device memory */
 int lk_get_sequence_results_device(lk_engine *e, const void **d_records, const void **d_guesses);
 /* the last window's records into a caller's device buffer, frame f at d_dst + f * dst_pitch_records records

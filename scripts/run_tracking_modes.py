@@ -23,6 +23,11 @@ for f in range(F):
     xd, yd = ca.speckle.deform(xs, ys, size, size, p)
     frames.append(np.ascontiguousarray(ca.speckle._render_torch(size, size, xd, yd, amps, 2.5, "cuda")))
 c = size / 2.0
+if os.environ.get("LK_PIN_FRAMES"):   # (tuning runs: page-locked frames - uploads return when enqueued)
+    import ctypes as C
+    lib = ca.load_library()
+    for f in frames:
+        assert lib.lk_pin_host_memory(C.c_void_p(f.ctypes.data), C.c_size_t(f.nbytes)) == 0
 if ANNULAR:
     for name, mode, host_rebuild in (("eulerian", tk.DEF_EULERIAN, False), ("lagrangian", tk.DEF_LAGRANGIAN, False),
                                      ("lagrangian, lists moved on the host", tk.DEF_LAGRANGIAN, True),

@@ -401,6 +401,7 @@ int lk_wait_sequence(lk_engine *e, lk_result *out) {
   e->win_outstanding = false;
   return 0;
 }
+int lk_sequence_prepare_host_records(lk_engine *, int n_frames) { return n_frames < 1 ? LK_ERROR_BAD_DOMAIN : 0; }
 int lk_sequence_host_records(lk_engine *e, const lk_result **records) {
   if (e->win_outstanding || e->win_records.empty())
     return LK_ERROR_BAD_DOMAIN;
