@@ -51,14 +51,20 @@ def means(path, kernel):
 d = means(sys.argv[1], "lk_solve_kernel<3, 2, 32, 64, false, false, false>")
 r = means(sys.argv[2], "lk_solve_kernel<3, 2, 16, 64, true, true, false>")
 tag = sys.argv[3]
-print(json.dumps({
+keep = {}
+try:   # (what scripts/profile_sequence.sh put into the committed file - the windows' constants and clocks - stays)
+    keep = json.load(open(f"profiles/{tag}_traffic.json"))
+except Exception:
+    pass
+keep.update({
     "solve_kernel_hbm_bytes_per_launch_C2": (d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0,
     "solve_kernel_valu_insts_per_launch_C2": d["SQ_INSTS_VALU"],
     "reference_order_hbm_bytes_per_launch_C2": (r["FETCH_SIZE"] + r["WRITE_SIZE"]) * 1024.0,
     "reference_order_valu_insts_per_launch_C2": r["SQ_INSTS_VALU"],
     "source": f"profiles/{tag}_pmc_summary.txt (lk_solve_kernel<3,2,32,64,false,false>) and profiles/{tag}_reforder_pmc.txt "
               "(lk_solve_kernel<3,2,16,64,true,true>): FETCH_SIZE + WRITE_SIZE in KiB per dispatch (these byte / dword loads read 1:1 on "
-              "the counter, calibrated on the pyramid kernel in profiles/r01_pmc_traffic.txt), SQ_INSTS_VALU summed over the device"}, indent=1))
+              "the counter, calibrated on the pyramid kernel in profiles/r01_pmc_traffic.txt), SQ_INSTS_VALU summed over the device"})
+print(json.dumps(keep, indent=1))
 PY
 timeout -k 10 200 rocprofv3 --kernel-trace -d "$out/c4" -o t -- python3 scripts/quick_solve.py C4 10 > "$out/c4.log" 2>&1
 { grep solve_ms "$out/c4.log"; python3 scripts/c4_chain_timeline.py "$out/c4/t_results.db" 8; } > "$out/${tag}_c4_chain.txt" 2>&1

@@ -29,6 +29,11 @@ def check_sequence_blocks(d, n1):
                 assert b["pipelined_instances"] is True and w["kernel_ms_per_pair"] > 0 and w["ms_per_pair"] >= w["kernel_ms_per_pair"]
                 assert abs(w["frac"] - w["algorithmic_bytes_per_pair"] / (w["kernel_ms_per_pair"] * 1e-3) / 1e9 / 8000.0) < 1e-9
                 assert w["speedup_vs_one_pair_at_a_time"] > 1.0
+                # (the windows' profile constants - profiles/r04_traffic.json, scripts/profile_sequence.sh - must reach the line:
+                # a refresh of the one-pair constants once dropped them and the line carried nulls)
+                if (cfg, mode) != ("C4", "reference_order"):   # (no counter pass of its own: config 4's default mode runs the same instance)
+                    assert 0.05 < (w.get("valu_issue_frac") or 0) < 1.0 and (w.get("traffic_hbm_bytes_per_pair") or 0) > 0, (cfg, mode)
+                    assert (w.get("measured_clock_GHz") or 0) > 1.0, (cfg, mode)
             ro = d["sequence"][cfg]["reference_order"]["one_pair_at_a_time"]
             assert ro["frames_with_identical_records"] == ro["of"] == d["sequence"][cfg]["reference_order"]["pairs"]
         assert d["end_to_end"]["ms_per_pair_one_new_frame_prefetched"] > 0
