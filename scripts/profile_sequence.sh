@@ -17,7 +17,7 @@ for wl in C2 C4; do
   echo "trace $wl done" >> "$out/progress.log"
 done
 : > "$out/${tag}_seq_pmc.txt"
-for cfg in "C2 default" "C2 reference_order" "C4 default" "C4 batch_invariant"; do
+for cfg in "C2 default" "C2 reference_order" "C4 default" "C4 reference_order" "C4 batch_invariant"; do
   set -- $cfg
   i=0
   for set in "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "FETCH_SIZE" "WRITE_SIZE"; do
@@ -28,15 +28,19 @@ for cfg in "C2 default" "C2 reference_order" "C4 default" "C4 batch_invariant"; 
   rm -rf "$out"/pmc*/
   echo "pmc $cfg done" >> "$out/progress.log"
 done
+: > "$out/${tag}_seq_wave_timeline.txt.new"
 for lib in build/tune/liblk_trace_seq32.so:C2:default build/tune/liblk_trace_seq16.so:C4:default build/tune/liblk_trace_seq16.so:C2:reference_order; do
   IFS=: read -r so wl mode <<< "$lib"
-  [ -f "$so" ] && LK_MODE=$mode LK_ENGINE_LIB=$PWD/$so timeout -k 10 200 python3 scripts/trace_sequence.py $wl 64 2>&1 | grep -v amdgpu.ids >> "$out/${tag}_seq_wave_timeline.txt" && echo >> "$out/${tag}_seq_wave_timeline.txt"
+  [ -f "$so" ] && LK_MODE=$mode LK_ENGINE_LIB=$PWD/$so timeout -k 10 200 python3 scripts/trace_sequence.py $wl 64 2>&1 | grep -v amdgpu.ids >> "$out/${tag}_seq_wave_timeline.txt.new" && echo >> "$out/${tag}_seq_wave_timeline.txt.new"
 done
+# (a timeline is kept only if the traced builds ran - stale or missing tuning libraries leave the committed one alone)
+if grep -q "clock" "$out/${tag}_seq_wave_timeline.txt.new" 2>/dev/null; then mv "$out/${tag}_seq_wave_timeline.txt.new" "$out/${tag}_seq_wave_timeline.txt"; else rm -f "$out/${tag}_seq_wave_timeline.txt.new"; fi
 # the windows' per-pair constants into <tag>_traffic.json (beside the one-pair constants of scripts/profile_round.sh, if that ran first)
 python3 - "$out/${tag}_seq_pmc.txt" "$out/${tag}_traffic.json" "$out/${tag}_seq_wave_timeline.txt" "$tag" <<'PY'
 import json, os, re, sys
 pmc, dst, timeline, tag = sys.argv[1:5]
-d = json.load(open(dst)) if os.path.exists(dst) else {}
+base = dst if os.path.exists(dst) else f"profiles/{tag}_traffic.json"   # (the committed file's other constants stay)
+d = json.load(open(base)) if os.path.exists(base) else {}
 valu, hbm = {}, {}
 for b in re.split(r"rocprofv3 --pmc passes", open(pmc).read())[1:]:
     m = re.search(r"window of 64 pairs, (\w+), LK_MODE=(\w+)", b)
@@ -46,6 +50,8 @@ for b in re.split(r"rocprofv3 --pmc passes", open(pmc).read())[1:]:
         valu[key] = vals["SQ_INSTS_VALU"] / 64
         if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
             hbm[key] = (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 / 64
+valu = dict({k: v for k, v in d.get("valu_insts_per_window_pair", {}).items() if k != "source"}, **valu)
+hbm = dict({k: v for k, v in d.get("hbm_bytes_per_window_pair", {}).items() if k != "source"}, **hbm)
 d["valu_insts_per_window_pair"] = dict(valu, source=f"profiles/{tag}_seq_pmc.txt: SQ_INSTS_VALU of one 64-pair window launch / 64")
 d["hbm_bytes_per_window_pair"] = dict(hbm, source=f"profiles/{tag}_seq_pmc.txt: (FETCH_SIZE + WRITE_SIZE) KiB of one 64-pair window launch / 64")
 clk = d.get("measured_clock_GHz", {"one_pair_C2": 2.07})
@@ -60,4 +66,4 @@ clk["source"] = f"profiles/{tag}_seq_wave_timeline.txt, profiles/*_wave_timeline
 d["measured_clock_GHz"] = clk
 json.dump(d, open(dst, "w"), indent=1)
 PY
-cat "$out/${tag}_seq_pmc.txt"; cat "$out/${tag}_seq_wave_timeline.txt"
+cat "$out/${tag}_seq_pmc.txt"; cat "$out/${tag}_seq_wave_timeline.txt" 2>/dev/null
