@@ -2882,8 +2882,8 @@ static int seq_group_of_class(const lk_engine *e, int c, int n) {
   if (g > 64)
     return -1;
   if (e->class_starved[c]) {
-    if (g != 16) // (starved levels inside the window: the 16-lane rows' finisher arithmetic)
-      return -1;
+    // (starved levels inside the window: the 16-lane rows' finisher arithmetic - whatever width the one-pair classifier
+    // promoted a class of few small sectors to, e.g. one rank's block of a sharded sequence: the rule below keeps big ones out)
     // ... which pays while the sectors are small.  Config 5's geometry (17 x 17 samples, one starved level of four) measured
     // 9.1 ms per pair in a window against 5.9 (default) / 7.4 (batch-invariant) for the one-pair chain, whose one-lane kernel
     // shares one instruction stream of the QR among 64 sectors and whose lane groups widen: such classes keep the chain, frame
@@ -2902,6 +2902,7 @@ static int seq_group_of_class(const lk_engine *e, int c, int n) {
     }
     if (n0 > (long long)big_n0 * n_starved)
       return -1;
+    return 16;
   }
   return g;
 }
@@ -3026,7 +3027,14 @@ static int launch_window(lk_engine *e, bool force_safe_flavour) {
         for (int i = e->class_begin[c]; i < e->class_begin[c + 1]; ++i)
           n0 += level0_count(e, (int)e->h_order[(size_t)i]);
         static const int small_n0 = [] { const char *f = std::getenv("LK_SEQ_SMALL"); return f ? std::atoi(f) : 64; }(); // tuning hook
-        if (n0 <= (long long)small_n0 * nc) {
+        // ... while the class is in the throughput regime.  With fewer sectors than lane-group rows are resident (12 288 at three
+        // wavefronts per SIMD: one rank's block of a sharded sequence) the window lasts as long as its slowest sector's chain, and
+        // the unified rows' steps are the shorter ones: blocks of config 4's grid, windows of 16 pairs, reference-order instance /
+        // unified rows: 25 088 sectors 0.77 / 0.82 ms per pair, 12 544: 0.67 / 0.61, 6272: 0.58 / 0.50, 3136: 0.54 / 0.48.
+        static const int latency_nc = [] { const char *f = std::getenv("LK_SEQ_LATENCY_SECTORS"); return f ? std::atoi(f) : 16384; }(); // tuning hook
+        // (and there the rows of a wavefront are better kept in step again - alignment never changes a bit: 6272 sectors, unified
+        // rows, aligned / not: 0.50 / 0.59 ms per pair)
+        if (n0 <= (long long)small_n0 * nc && nc > latency_nc) {
           a.align = 0;
           if (!safe_flavour(e) && !force_safe_flavour) {
             flavour = 2;

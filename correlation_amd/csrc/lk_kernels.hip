@@ -4220,7 +4220,16 @@ static hipError_t launch_solve_seq_gs(const LkSolveArgs &a, hipStream_t st) {
     return f ? atoi(f) : 0;
   }();
   const int fill_permille = fill_env > 0 ? fill_env : (REF && GROUP == 16 ? 1250 : 640);
-  const int fill = (int)(((long long)a.n_sectors * fill_permille / 1000 + per_wg - 1) / per_wg);
+  long long groups = (long long)a.n_sectors * fill_permille / 1000;
+  // Few sectors (one rank's block of a sharded sequence): the launch is bound by the chains of its sectors, not by throughput,
+  // and a sector without a group of its own only waits its turn - every sector gets one while that fills no more than half
+  // of the resident groups.  Measured on blocks of config 2's grid, windows of 16 pairs (scripts/experiments/shard_latency*.sh):
+  // 5000 sectors 640 / 820 / 1000 per mille -> 0.134 / 0.121 / 0.132 ms per pair, 2500: 0.121 / 0.104 / 0.101, 1250: 0.088 / - / 0.072.
+  if (fill_env <= 0 && fill_permille < 1000) {
+    const long long own = std::min<long long>(a.n_sectors, (long long)resident * per_wg / 2);
+    groups = std::max(groups, own);
+  }
+  const int fill = (int)((groups + per_wg - 1) / per_wg);
   int grid = fill < resident ? fill : resident;
   static const int grid_permille = [] { // tuning hook: the grid as a share of that
     const char *f = getenv("LK_SEQ_GRID");
