@@ -14,7 +14,7 @@ from correlation_amd.workload import C2, C4, C4B, shard_range  # noqa: E402
 
 wl = {"C2": C2, "C4": C4, "C4B": C4B}[sys.argv[1] if len(sys.argv) > 1 else "C4"]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-K = 16
+K = int(os.environ.get("LK_K", 16))
 frames = np.stack(ca.speckle.speckle_sequence(wl.size, wl.size, n + 1, velocity=(0.8, -0.4), dilation=1e-4, seed=7, device="cuda"))
 c = (wl.size / 2 - 0.5, wl.size / 2 - 0.5)
 zero = np.zeros(6, np.float32)
