@@ -192,6 +192,31 @@ def test_default_mode_window_stays_with_the_loop(frames448):
     b.close()
 
 
+def test_small_blocks_of_small_sectors_keep_their_pipelined_instance(frames448):
+    """One rank's block of a sharded sequence: a few thousand 9 x 9-sample sectors.  The one-pair classifier promotes such a
+    class to wider lane groups (too few wavefronts to fill the chip); inside a window it must still run on the 16-lane rows
+    that solve its starved level - it used to fall back to frame-after-frame launches (1.0 against 0.54 ms per pair on a
+    quarter of the 9 x 9 grid).  Default mode: the loop's results within the mode's tolerance."""
+    frames, n, c = frames448, 6, (223.5, 223.5)
+    a, b = make_engine("default"), make_engine("default")
+    for e in (a, b):
+        e.set_undeformed_image(frames[0])
+        e.set_rect_grid(24.0, 24.0, 423.0, 423.0, 40, 40)   # 40 x 40 sectors of 9 x 9 samples (pitch 9.98): levels of 81 / 25 / 9
+        e.commit_sectors()
+    assert a.sector_info(0)[0] == 81
+    _, r_loop = loop(a, frames, 0, n, center=c)
+    b.sequence_reserve(n)
+    _, r_win = window(b, frames, 0, n, center=c)
+    assert b.sequence_is_pipelined
+    same = r_win["error_code"] == r_loop["error_code"]
+    assert same.mean() > 0.995
+    ok = same & (r_loop["error_code"] == 0)
+    d = np.abs(r_win["p"] - r_loop["p"])[ok][:, :2].max(1)
+    assert np.percentile(d, 99) < 0.08 and np.median(d) < 1e-4, (np.percentile(d, 99), np.median(d))   # (the bound of the one-pair default-mode tests on such sectors)
+    a.close()
+    b.close()
+
+
 def test_domains_without_a_pipelined_instance_run_frame_after_frame(frames448):
     """a sector of more than 8192 samples (workgroup-wide lane group): same interface, the one-pair launches underneath"""
     frames, n, c = frames448, 4, (223.5, 223.5)
